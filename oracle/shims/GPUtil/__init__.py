@@ -1,0 +1,1 @@
+"""TEST INFRASTRUCTURE ONLY -- empty oracle shim."""
