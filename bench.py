@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- RAVE v2 training step on MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--phase vae|gan]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete ``training_step`` (rave/model.py:288-413) of the v2 config on a synthetic
+minibatch already resident in HBM: PQMF analysis -> EncoderV2 -> reparametrize -> GeneratorV2 ->
+PQMF synthesis -> multi-scale STFT losses -> backward -> Adam.  Default workload = BASELINE.json
+configs[1]: v2, batch 32 mono, 44.1 kHz, n_signal 65536, VAE phase.  Multi-GPU: weak scaling, the
+minibatch is sharded (32 clips per GPU), gradients averaged with bucketed RCCL all-reduce
+overlapped with backward.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# SURVEY.md section 8d contract figures for v2 forward (PQMF -> enc -> dec -> PQMF^-1), per mono clip
+V2_FWD_MAC_PER_CLIP = 4_786_814_976
+V2_FWD_ACT_BYTES_PER_CLIP = 83_673_088
+V2_WEIGHT_BYTES = 126_123_072
+HBM_PEAK = 8.0e12          # B/s   MI355X_MICROARCH.md chip-level parameters
+F32_MFMA_PEAK = 157.3e12   # FLOP/s (f32-input MFMA == f32 vector peak)
+
+
+def cpu_baseline(n_signal: int, budget_s: float = 20.0):
+    """The oracle (CPU fp32 ATen restatement of the reference, oracle/rave_oracle.py) timed on this
+    box's host cores on a bounded sample of the same workload (v2 VAE-phase step)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rave_oracle as O
+    cfg = O.v2_config()
+    sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if k.startswith(("encoder.", "decoder."))}
+    full = dict(sd)
+    full.update(leaves)
+    opt = torch.optim.Adam(list(leaves.values()), 1e-3, (.5, .9))
+    b = 2
+    x = O.synthetic_batch(b, 1, n_signal)
+    eps = torch.randn(b, cfg.latent_size, n_signal // 2048)
+    times = []
+    t_start = time.perf_counter()
+    for i in range(6):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        loss, _, _, _ = O.generator_losses(xx, full, cfg, eps, warmed_up=False)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 2:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": b * n_signal / med, "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"v2 VAE-phase training step (fwd+losses+bwd+Adam), batch {b} x {n_signal} samples, "
+                      f"median of {len(times)} steps after 1 warm-up, torch CPU fp32 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--n-signal", type=int, default=65536)
+    ap.add_argument("--phase", choices=["vae", "gan"], default="vae")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rave_amd import ddp, model as M, ops
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+    torch.manual_seed(0)
+    m = M.build_v2().to(dev).train()
+    ddp.broadcast_module(m)
+    gen_opt, dis_opt = m.configure_optimizers()
+    m.warmed_up = args.phase == "gan"
+    gen_params = list(m.encoder.parameters()) + list(m.decoder.parameters())
+    red_gen = ddp.GradReducer(gen_params) if world > 1 else None
+    red_dis = ddp.GradReducer(list(m.discriminator.parameters())) if world > 1 and m.warmed_up else None
+
+    # synthetic 44.1 kHz waveforms, one shard per rank, resident in HBM
+    g = torch.Generator().manual_seed(20250509 + rank)
+    t = torch.arange(args.n_signal, dtype=torch.float32) / 44100.0
+    x = 0.1 * torch.randn(args.batch, 1, args.n_signal, generator=g)
+    for f0, a in ((220.0, 0.2), (1760.0, 0.1), (7040.0, 0.05)):
+        ph = torch.rand(args.batch, 1, 1, generator=g) * 6.283185307
+        x = x + a * torch.sin(6.283185307 * f0 * t + ph)
+    x = x.clamp(-1, 1).to(dev)
+
+    def step(i):
+        if world > 1:
+            dis_step = m.warmed_up and not (i % m.update_discriminator_every)
+            red = red_dis if dis_step else red_gen
+            red.begin()
+            m.training_step(x.detach().clone(), i, grad_sync=lambda idx: red.finish())
+        else:
+            m.training_step(x.detach().clone(), i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    samples = world * args.batch * args.n_signal * args.steps
+
+    out = {
+        "metric": "audio samples/sec/GPU (RAVE v2 training step, 44.1 kHz, n_signal=65536)",
+        "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"v2 config, batch {args.batch} mono 44.1 kHz n_signal={args.n_signal}, "
+                               f"{'VAE' if args.phase == 'vae' else 'VAE+GAN'}-phase training step per GPU",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+        "per_gpu_samples_per_s": samples / dt / world,
+    }
+
+    if rank == 0 and not args.no_kernel_timing:
+        # ---- per-launch HIP-event timing of the conv kernels over instrumented replays of the step
+        reps = 2
+        ops.profile_begin()
+        for i in range(reps):
+            step(args.warmup + args.steps + i)
+        rec = ops.profile_end()
+        agg = {}
+        for kind, fl, by, ms in rec:
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
+        dom = max(agg, key=lambda k: agg[k][3])
+        n, fl, by, ms = agg[dom]
+        out["roofline"] = {
+            "bound": "mfma", "kernel": {"conv_fwd": "conv_igemm_kernel (forward launches)",
+                                        "conv_dgrad": "conv_igemm_kernel (data-gradient launches)",
+                                        "conv_wgrad": "wgrad_kernel"}[dom],
+            "achieved": fl / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": fl / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": None,
+            "launches_per_step": n // reps, "avg_launch_ms": ms / n,
+            "algorithmic_gflop_per_launch": fl / n / 1e9,
+            "note": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32); HIP events on the launch stream around "
+                    "every launch of the kernel family with the largest total time",
+        }
+        out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
+                                      "tflops": v[1] / (v[3] * 1e-3) / 1e12,
+                                      "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}
+        # ---- forward-only leg of the north-star target (PQMF + conv stacks, no_grad)
+        with torch.no_grad():
+            for _ in range(2):
+                m.decode(m.encoder.reparametrize(m.encode(x))[0])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            nf = 5
+            for _ in range(nf):
+                m.decode(m.encoder.reparametrize(m.encode(x))[0])
+            e1.record()
+            torch.cuda.synchronize()
+            t_fwd = e0.elapsed_time(e1) * 1e-3 / nf
+        fb = args.batch * V2_FWD_ACT_BYTES_PER_CLIP * (args.n_signal / 65536) + V2_WEIGHT_BYTES
+        ff = 2.0 * args.batch * V2_FWD_MAC_PER_CLIP * (args.n_signal / 65536)
+        out["forward_only"] = {"ms": t_fwd * 1e3, "algorithmic_bytes": fb, "algorithmic_flop": ff,
+                               "hbm_roofline_frac": fb / t_fwd / HBM_PEAK,
+                               "f32_mfma_frac": ff / t_fwd / F32_MFMA_PEAK,
+                               "samples_per_s": args.batch * args.n_signal / t_fwd}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.n_signal)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * rave_hip.h -- C ABI of librave_hip.so: the MI355X (gfx950 / CDNA4) hot path of RAVE.
+ *
+ * The reference (acids-ircam/RAVE) has NO native/FFI interface: its "operator API" for this
+ * path is the set of Python leaf-module signatures that gin hands to rave.model.RAVE
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the reference *Python* site it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer would add on the reference
+ * side.  All citations are relative to the reference tree.
+ *
+ * Conventions
+ *   - tensors are contiguous fp32, layout (B, C, L) with L innermost (PyTorch default);
+ *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch caching allocator in
+ *     the Python binding); the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - return value: RH_OK (0), <0 = invalid / unsupported argument (nothing enqueued),
+ *     >0 = hipError_t of the failed launch; rh_last_error() gives a thread-local message;
+ *   - re-entrant: no mutable global state (forward runs on the Python thread, backward on
+ *     PyTorch's autograd thread with the GIL released by ctypes).
+ */
+#ifndef RAVE_HIP_H
+#define RAVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_VERSION 100 /* 0.1.0 */
+
+#define RH_OK 0
+#define RH_ERR_INVALID (-1)     /* inconsistent descriptor / null pointer */
+#define RH_ERR_UNSUPPORTED (-2) /* valid but not implemented (e.g. groups != 1) */
+#define RH_ERR_WORKSPACE (-3)   /* workspace too small; see rh_conv1d_workspace_bytes */
+
+typedef void* rh_stream_t; /* hipStream_t */
+
+/* Activation fused on the conv INPUT (the reference applies it as a separate nn.Module right
+ * before the conv: rave/blocks.py:93-105 DilatedUnit, :559, :578, :648, :673). */
+enum rh_act {
+    RH_ACT_NONE = 0,
+    RH_ACT_LEAKY = 1, /* nn.LeakyReLU(slope)          rave/blocks.py:90,527,612; discriminator.py:101 */
+    RH_ACT_SNAKE = 2  /* x + sin^2(a x)/(a+1e-9)      rave/blocks.py:852-860 (per-channel alpha)      */
+};
+
+/*
+ * One 1-D convolution geometry.  Replaces cached_conv.Conv1d / cached_conv.ConvTranspose1d as
+ * used by the reference (call sites: rave/pqmf.py:256-273, rave/blocks.py:96-108,536-592,
+ * 637-692) and torch.nn.Conv1d / torch.nn.Conv2d with (k,1) kernels as used by the
+ * discriminators (rave/discriminator.py:77-119,174-195).
+ *
+ * transposed == 0:  y[b,co,l] = bias[co] + sum_{ci,t} w[co,ci,t] * act(x)[b,ci, l*stride + t*dilation - pad_left]
+ *                   (zero outside [0,l_in)); pad_right is implied by l_out.            w: (c_out, c_in, kernel)
+ * transposed == 1:  torch conv_transpose1d(act(x), w, stride, padding=pad_left)         w: (c_in, c_out, kernel)
+ *                   l_out = (l_in-1)*stride - 2*pad_left + kernel ; dilation must be 1.
+ *
+ * inner > 1 describes a Conv2d with kernel (k,1), stride (s,1), padding (p,0) on a (B,C,H,W)
+ * tensor with W == inner (MultiPeriodDiscriminator, rave/discriminator.py:186-195): l_in/l_out
+ * are H_in/H_out and every position is `inner` contiguous elements.  in_valid (0 = all) is the
+ * number of leading elements of each (b,c) input row that are real data; the remainder reads as
+ * zero (this is MultiPeriodDiscriminator.fold's zero pad, done in-kernel).
+ */
+typedef struct rh_conv1d_desc {
+    int32_t batch;
+    int32_t c_in;
+    int32_t c_out;
+    int32_t l_in;
+    int32_t l_out;
+    int32_t kernel;
+    int32_t stride;
+    int32_t dilation;
+    int32_t pad_left;
+    int32_t transposed;
+    int32_t groups;   /* must be 1 */
+    int32_t inner;    /* 1 for Conv1d */
+    int32_t in_valid; /* 0 = l_in*inner */
+    int32_t act;      /* enum rh_act, fused on the conv input */
+    float act_slope;  /* LeakyReLU slope */
+} rh_conv1d_desc;
+
+int rh_version(void);
+const char* rh_last_error(void);
+
+/* ---- weight preparation --------------------------------------------------------------- */
+
+/* torch.nn.utils.weight_norm(dim=0) as applied by rave/blocks.py:15-22 `normalization`:
+ *   w[r,:] = g[r] * v[r,:] / ||v[r,:]||_2 , rows = size of dim 0, cols = product of the others
+ *   (dim 0 = out-channels for Conv1d, IN-channels for ConvTranspose1d).  norms[r] = ||v[r,:]||. */
+int rh_weight_norm_fwd_f32(const float* v, const float* g, int64_t rows, int64_t cols, float* w,
+                           float* norms, rh_stream_t stream);
+/* backward of the above: dv, dg from dw (torch _weight_norm_interface_backward). */
+int rh_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norms,
+                           int64_t rows, int64_t cols, float* dv, float* dg, rh_stream_t stream);
+
+/* Number of floats of the two packed (MFMA-friendly, K-major) copies of a weight tensor:
+ * which = 0 -> operand of rh_conv1d_fwd_f32, which = 1 -> operand of rh_conv1d_bwd_data_f32. */
+int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which);
+/* Repack w (PyTorch layout, see rh_conv1d_desc) into wp_fwd and/or wp_bwd (either may be NULL). */
+int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd, float* wp_bwd,
+                       rh_stream_t stream);
+
+/* ---- convolution ---------------------------------------------------------------------- */
+
+/* y = conv(act(x)) + bias + residual.   bias (c_out), residual (B,c_out,l_out*inner) and
+ * snake_alpha (c_in) may be NULL.  Replaces `act -> cc.Conv1d -> (+ x)` of DilatedUnit /
+ * Residual (rave/blocks.py:31-45,83-112) and every other `activation; conv` pair of
+ * EncoderV2 / GeneratorV2 / discriminator.ConvNet. */
+int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_fwd,
+                      const float* bias, const float* snake_alpha, const float* residual,
+                      float* y, rh_stream_t stream);
+
+/* dx = act'(x) * conv_bwd_data(dy) + add.   `x` is the forward input (needed when act != NONE),
+ * `add` (B,c_in,l_in*inner) may be NULL (residual-branch gradient). */
+int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd,
+                           const float* x, const float* snake_alpha, const float* add, float* dx,
+                           rh_stream_t stream);
+
+/* Bytes of scratch rh_conv1d_bwd_weight_f32 needs for this geometry. */
+int64_t rh_conv1d_workspace_bytes(const rh_conv1d_desc* d);
+/* dw (PyTorch weight layout) = sum_{b,l} dy (x) act(x);  dbias (c_out, may be NULL) = sum dy.
+ * Deterministic: split-K partials in `workspace`, then an ordered reduction. */
+int rh_conv1d_bwd_weight_f32(const rh_conv1d_desc* d, const float* dy, const float* x,
+                             const float* snake_alpha, float* dw, float* dbias, void* workspace,
+                             int64_t workspace_bytes, rh_stream_t stream);
+
+/* ---- PQMF (rave/pqmf.py CachedPQMF, 16 bands) ------------------------------------------- */
+
+/* CachedPQMF.forward (rave/pqmf.py:279-283): strided Conv1d(1,M,K,stride=M,pad=(pad_left,*))
+ * followed by reverse_half (:13-17).  x (rows, T) -> y (rows, M, n_frames) with
+ * n_frames = (T + pad_left + pad_right - K)/M + 1.  w: forward_conv.weight (M,1,K). M must be 16. */
+int rh_pqmf_analysis_fwd_f32(const float* x, const float* w, int32_t rows, int32_t t_len,
+                             int32_t n_band, int32_t kernel, int32_t pad_left, int32_t n_frames,
+                             float* y, rh_stream_t stream);
+/* gradient of the above w.r.t. x. */
+int rh_pqmf_analysis_bwd_f32(const float* dy, const float* w, int32_t rows, int32_t t_len,
+                             int32_t n_band, int32_t kernel, int32_t pad_left, int32_t n_frames,
+                             float* dx, rh_stream_t stream);
+/* CachedPQMF.inverse (rave/pqmf.py:285-294): reverse_half, Conv1d(M,M,K2,pad=(pad_left,*)) * M,
+ * band flip and interleave.  y (rows, M, n_frames) -> x (rows, n_out*M); n_out = n_frames +
+ * pad_left + pad_right - K2 + 1.  w: inverse_conv.weight (M,M,K2). */
+int rh_pqmf_synthesis_fwd_f32(const float* y, const float* w, int32_t rows, int32_t n_frames,
+                              int32_t n_band, int32_t kernel, int32_t pad_left, int32_t n_out,
+                              float* x, rh_stream_t stream);
+/* gradient of the above w.r.t. y. */
+int rh_pqmf_synthesis_bwd_f32(const float* dx, const float* w, int32_t rows, int32_t n_frames,
+                              int32_t n_band, int32_t kernel, int32_t pad_left, int32_t n_out,
+                              float* dy, rh_stream_t stream);
+
+/* ---- small fused elementwise ops ------------------------------------------------------- */
+
+/* GeneratorV2 output head (rave/blocks.py:705-711): y = tanh(a * sigmoid(m)), with
+ * x = [a | m] split on the channel axis: x (B, 2C, L) -> y (B, C, L). */
+int rh_amp_tanh_fwd_f32(const float* x, int32_t batch, int32_t c, int32_t l, float* y,
+                        rh_stream_t stream);
+int rh_amp_tanh_bwd_f32(const float* dy, const float* x, int32_t batch, int32_t c, int32_t l,
+                        float* dx, rh_stream_t stream);
+/* Standalone activation (used where no conv follows). n = total elements, c/l for snake. */
+int rh_act_fwd_f32(const float* x, const float* snake_alpha, int32_t act, float slope,
+                   int32_t batch, int32_t c, int32_t l, float* y, rh_stream_t stream);
+/* nn.functional.avg_pool1d(x, 2) of MultiScaleDiscriminator (rave/discriminator.py:135). */
+int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
+int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAVE_HIP_H */

@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.pt from the UNMODIFIED reference
+(/root/reference, imported through oracle/ref_import.py) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference holds no golden vectors of its own for this path (shape-only
+tests); these fixtures are outputs of the reference's own modules on seeded inputs and pin both
+the oracle restatement (tests/test_oracle.py, CPU) and the HIP path (tests/test_gpu_parity.py).
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+from ref_models import attach_optimizers, build_reference_rave  # noqa: E402
+import rave_oracle as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+torch.set_num_threads(8)
+
+
+def t(x):
+    return x.detach().clone().contiguous()
+
+
+def golden_pqmf():
+    torch.manual_seed(0)
+    m = build_reference_rave("v2", capacity=4, latent_size=8)
+    pq = m.pqmf
+    x = O.synthetic_batch(3, 1, 4096, seed=7)
+    with torch.no_grad():
+        y = pq(x.reshape(-1, 1, x.shape[-1]))
+        xr = pq.inverse(y)
+    # gradients of both directions w.r.t. their inputs under a fixed cotangent
+    g = torch.Generator().manual_seed(11)
+    cy = torch.randn(y.shape, generator=g)
+    cx = torch.randn(xr.shape, generator=g)
+    xa = x.reshape(-1, 1, x.shape[-1]).clone().requires_grad_(True)
+    (pq(xa) * cy).sum().backward()
+    ya = y.clone().requires_grad_(True)
+    (pq.inverse(ya) * cx).sum().backward()
+    out = dict(h=t(pq.h), hk=t(pq.hk), w_fwd=t(pq.forward_conv.weight), w_inv=t(pq.inverse_conv.weight),
+               x=t(x), y=t(y), x_rec=t(xr), cot_y=cy, cot_x=cx, grad_x=t(xa.grad), grad_y=t(ya.grad))
+    # causal overlay (configs/causal.gin)
+    mc = build_reference_rave("v2", capacity=4, latent_size=8, causal=True)
+    with torch.no_grad():
+        yc = mc.pqmf(x.reshape(-1, 1, x.shape[-1]))
+        xc = mc.pqmf.inverse(yc)
+    out.update(y_causal=t(yc), x_rec_causal=t(xc))
+    build_reference_rave("v2", capacity=4, latent_size=8, causal=False)  # reset gin binding
+    torch.save(out, os.path.join(OUT, "pqmf.pt"))
+    print("pqmf.pt", {k: tuple(v.shape) for k, v in out.items()})
+
+
+SELECT = [
+    "encoder.encoder.net.0.weight_v", "encoder.encoder.net.0.weight_g",
+    "encoder.encoder.net.1.aligned.branches.0.net.1.weight_v",
+    "encoder.encoder.net.1.aligned.branches.0.net.3.weight_g",
+    "encoder.encoder.net.5.weight_v",
+    "decoder.net.0.weight_v", "decoder.net.2.weight_v", "decoder.net.2.weight_g",
+    "decoder.net.3.aligned.branches.0.net.1.weight_v", "decoder.net.21.weight_v",
+    "discriminator.discriminators.0.layers.0.net.0.weight_v",
+    "discriminator.discriminators.0.layers.0.net.0.bias",
+    "discriminator.discriminators.0.layers.4.net.4.weight_v",
+    "discriminator.discriminators.0.layers.2.net.8.weight",
+    "discriminator.discriminators.1.layers.0.net.0.weight_v",
+    "discriminator.discriminators.1.layers.2.net.6.weight_g",
+    "discriminator.discriminators.1.layers.1.net.8.bias",
+]
+
+
+def grads_of(model):
+    named = dict(model.named_parameters())
+    return {k: t(named[k].grad) for k in SELECT if named[k].grad is not None}
+
+
+def golden_v2_tiny(causal=False, name="v2_tiny.pt"):
+    cap, lat, n_signal, batch = 6, 8, 32768, 2
+    torch.manual_seed(0)
+    m = build_reference_rave("v2", capacity=cap, latent_size=lat, causal=causal)
+    m.train()
+    attach_optimizers(m)
+    sd = {k: t(v) for k, v in m.state_dict().items()
+          if k.startswith(("pqmf.", "encoder.", "decoder.", "discriminator."))}
+    x = O.synthetic_batch(batch, 1, n_signal, seed=3)
+    out = dict(config=dict(capacity=cap, latent_size=lat, causal=causal, n_signal=n_signal, batch=batch),
+               state_dict=sd, x=t(x))
+    # forward products with injected noise (first RNG draw of the step is randn_like(mean))
+    with torch.no_grad():
+        zp, x_mb = m.encode(x, return_mb=True)
+        torch.manual_seed(1234)
+        z, reg = m.encoder.reparametrize(zp)[:2]
+        torch.manual_seed(1234)
+        eps = torch.randn(z.shape)
+        y_mb = m.decoder(z)
+        y_raw = m.decode(z)
+        feats = m.discriminator(torch.cat([x, y_raw], 0))
+    out.update(eps=eps, x_mb=t(x_mb), z_params=t(zp), z=t(z), reg=t(reg), y_mb=t(y_mb), y_raw=t(y_raw),
+               feat_last=[t(f[-1]) for f in feats], feat_mid=[t(f[2]) for f in feats])
+    # VAE-phase step (warmed_up False): rave/model.py:288-413 run by the reference itself
+    m.warmed_up = False
+    torch.manual_seed(1234)
+    m.training_step(x.clone(), 0)
+    out["vae"] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)}, grads=grads_of(m))
+    # GAN phase from the SAME initial weights
+    m.load_state_dict({**m.state_dict(), **sd})
+    attach_optimizers(m)
+    m.zero_grad(set_to_none=True)
+    m.warmed_up = True
+    torch.manual_seed(1234)
+    m.training_step(x.clone(), 0)   # discriminator step (0 % 4 == 0)
+    out["dis"] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)}, grads=grads_of(m))
+    m.load_state_dict({**m.state_dict(), **sd})
+    attach_optimizers(m)
+    m.zero_grad(set_to_none=True)
+    m.warmed_up = True
+    torch.manual_seed(1234)
+    m.training_step(x.clone(), 1)   # generator step
+    out["gen"] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)}, grads=grads_of(m))
+    torch.save(out, os.path.join(OUT, name))
+    nbytes = os.path.getsize(os.path.join(OUT, name))
+    print(name, nbytes, "bytes;", {k: float(v) for k, v in out["vae"]["losses"].items()})
+    if causal:
+        build_reference_rave("v2", capacity=cap, latent_size=lat, causal=False)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    golden_pqmf()
+    golden_v2_tiny(False, "v2_tiny.pt")
+    golden_v2_tiny(True, "v2_tiny_causal.pt")

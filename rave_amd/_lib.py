@@ -1,0 +1,80 @@
+"""ctypes binding of librave_hip.so (the C ABI declared in include/rave_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing
+this module raises, and every op raises on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: librave_hip.so binds to the libamdhip64 torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librave_hip.so")
+
+ACT_NONE, ACT_LEAKY, ACT_SNAKE = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``rh_conv1d_desc`` (include/rave_hip.h)."""
+    _fields_ = [
+        ("batch", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32),
+        ("l_in", C.c_int32), ("l_out", C.c_int32), ("kernel", C.c_int32),
+        ("stride", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32),
+        ("transposed", C.c_int32), ("groups", C.c_int32), ("inner", C.c_int32),
+        ("in_valid", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"rave_amd: {LIB_PATH} not found. Build it with `python -m rave_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU / PyTorch fallback for the HIP hot path.")
+    lib = C.CDLL(LIB_PATH)
+    P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    D = C.POINTER(ConvDesc)
+    sig = {
+        "rh_version": ([], C.c_int),
+        "rh_last_error": ([], C.c_char_p),
+        "rh_weight_norm_fwd_f32": ([P, P, I64, I64, P, P, P], C.c_int),
+        "rh_weight_norm_bwd_f32": ([P, P, P, P, I64, I64, P, P, P], C.c_int),
+        "rh_conv1d_packed_floats": ([D, C.c_int], I64),
+        "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
+        "rh_conv1d_fwd_f32": ([D, P, P, P, P, P, P, P], C.c_int),
+        "rh_conv1d_bwd_data_f32": ([D, P, P, P, P, P, P, P], C.c_int),
+        "rh_conv1d_workspace_bytes": ([D], I64),
+        "rh_conv1d_bwd_weight_f32": ([D, P, P, P, P, P, P, I64, P], C.c_int),
+        "rh_pqmf_analysis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
+        "rh_pqmf_analysis_bwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
+        "rh_pqmf_synthesis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
+        "rh_pqmf_synthesis_bwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
+        "rh_amp_tanh_fwd_f32": ([P, I32, I32, I32, P, P], C.c_int),
+        "rh_amp_tanh_bwd_f32": ([P, P, I32, I32, I32, P, P], C.c_int),
+        "rh_act_fwd_f32": ([P, P, I32, F, I32, I32, I32, P, P], C.c_int),
+        "rh_avgpool2_fwd_f32": ([P, I64, I32, P, P], C.c_int),
+        "rh_avgpool2_bwd_f32": ([P, I64, I32, P, P], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.argtypes = args
+        fn.restype = res
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.rh_last_error().decode(errors="replace")
+        raise RuntimeError(f"librave_hip {what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

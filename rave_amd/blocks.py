@@ -1,0 +1,286 @@
+"""Drop-in mirrors of the reference's hot-path blocks (rave/blocks.py) on the HIP kernels.
+
+Constructor signatures, module trees and therefore ``state_dict`` keys/shapes equal the
+reference's (e.g. ``net.1.aligned.branches.0.net.1.weight_v``), so checkpoints are
+interchangeable.  Execution is fused: every ``activation -> conv`` pair becomes one kernel call
+(activation applied while staging the input tile), ``Residual(DilatedUnit)`` is a single
+autograd node with the residual add in the second conv's epilogue, and weight norm runs in its
+own HIP kernel.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import cc, ops
+from .ops import ACT_LEAKY, ACT_NONE, ACT_SNAKE
+
+_NORMALIZATION_MODE = "weight_norm"  # configs/v1.gin:41 ``blocks.normalization.mode = 'weight_norm'``
+
+
+def set_normalization_mode(mode: str) -> None:
+    global _NORMALIZATION_MODE
+    if mode not in ("identity", "weight_norm"):
+        raise Exception(f"Normalization mode {mode} not supported")
+    _NORMALIZATION_MODE = mode
+
+
+def weight_norm(module: nn.Module, name: str = "weight", dim: int = 0) -> nn.Module:
+    """Same parametrisation and parameter names as ``torch.nn.utils.weight_norm`` (``weight_g`` with
+    shape (rows,1,..), ``weight_v``); the product g v/||v|| is computed by rh_weight_norm_fwd_f32
+    inside the conv modules' forward (cc._effective_weight)."""
+    if dim != 0:
+        raise NotImplementedError("rave_amd weight_norm: dim must be 0 (what the reference uses)")
+    w = getattr(module, name)
+    del module._parameters[name]
+    dims = tuple(range(1, w.dim()))
+    g = w.detach().pow(2).sum(dims, keepdim=True).sqrt()
+    module.register_parameter(name + "_g", nn.Parameter(g))
+    module.register_parameter(name + "_v", nn.Parameter(w.detach().clone()))
+    return module
+
+
+def remove_weight_norm(module: nn.Module, name: str = "weight") -> nn.Module:
+    g = module._parameters.pop(name + "_g")
+    v = module._parameters.pop(name + "_v")
+    module.register_parameter(name, nn.Parameter(torch._weight_norm(v.detach(), g.detach(), 0)))
+    return module
+
+
+def normalization(module: nn.Module, mode: Optional[str] = None):
+    """rave/blocks.py:15-22."""
+    mode = mode or _NORMALIZATION_MODE
+    if mode == "identity":
+        return module
+    if mode == "weight_norm":
+        return weight_norm(module)
+    raise Exception(f"Normalization mode {mode} not supported")
+
+
+class Snake(nn.Module):
+    """rave/blocks.py:852-860.  Standalone form (torch ops, differentiable in alpha); convs fuse it."""
+
+    def __init__(self, dim: int) -> None:
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(dim, 1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x + (self.alpha + 1e-9).reciprocal() * (self.alpha * x).sin().pow(2)
+
+
+def _act_of(m: nn.Module):
+    """(act code, slope, alpha) of an activation module, or None if ``m`` is not one."""
+    if isinstance(m, nn.LeakyReLU):
+        return ACT_LEAKY, float(m.negative_slope), None
+    if isinstance(m, Snake):
+        return ACT_SNAKE, 0.0, m.alpha
+    return None
+
+
+class AdaptiveInstanceNormalization(nn.Module):
+    """rave/blocks.py:863-926: identity in training mode (:901-902); buffers kept for state_dict
+    compatibility.  Inference-time style transfer is out of the training hot path."""
+
+    def __init__(self, dim: int) -> None:
+        super().__init__()
+        for n in ("x", "y"):
+            self.register_buffer(f"mean_{n}", torch.zeros(cc.MAX_BATCH_SIZE, dim, 1))
+            self.register_buffer(f"std_{n}", torch.ones(cc.MAX_BATCH_SIZE, dim, 1))
+            self.register_buffer(f"learn_{n}", torch.zeros(1))
+            self.register_buffer(f"num_update_{n}", torch.zeros(1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            return x
+        raise NotImplementedError("rave_amd AdaIN: eval-mode statistics transfer is not on the training hot path")
+
+
+class DilatedUnit(nn.Module):
+    """rave/blocks.py:83-112: act -> WN(Conv k dil d) -> act -> WN(Conv 1x1)."""
+
+    def __init__(self, dim: int, kernel_size: int, dilation: int,
+                 activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2)) -> None:
+        super().__init__()
+        net = [
+            activation(dim),
+            normalization(cc.Conv1d(dim, dim, kernel_size=kernel_size, dilation=dilation, bias=False,
+                                    padding=cc.get_padding(kernel_size, dilation=dilation))),
+            activation(dim),
+            normalization(cc.Conv1d(dim, dim, kernel_size=1, bias=False)),
+        ]
+        self.net = cc.CachedSequential(*net)
+        self.cumulative_delay = net[1].cumulative_delay
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return run_fused(self.net, x)
+
+
+class Residual(nn.Module):
+    """rave/blocks.py:31-45.  When the wrapped module is a DilatedUnit the whole
+    ``x + Conv1(act(Conv3(act(x))))`` runs as one fused autograd node."""
+
+    def __init__(self, module, cumulative_delay=0):
+        super().__init__()
+        additional_delay = module.cumulative_delay
+        self.aligned = cc.AlignBranches(module, nn.Identity(), delays=[additional_delay, 0])
+        self.cumulative_delay = additional_delay + cumulative_delay
+
+    def forward(self, x):
+        unit = self.aligned.branches[0]
+        if isinstance(unit, DilatedUnit):
+            a0, c3, a2, c1 = unit.net[0], unit.net[1], unit.net[2], unit.net[3]
+            f0, f2 = _act_of(a0), _act_of(a2)
+            if f0 is not None and f2 is not None and f0[2] is None and f2[2] is None:
+                return ops.residual_unit(x, cc._effective_weight(c3), cc._effective_weight(c1),
+                                         c3.geom(f0[0], f0[1]), c1.geom(f2[0], f2[1]))
+            # Snake: alpha needs its own gradient -> unfused activation, fused residual add
+            h = c3(a0(x))
+            return c1(a2(h), residual=x)
+        x_net, x_res = self.aligned(x)
+        return x_net + x_res
+
+
+_CONV_TYPES = (cc.Conv1d, cc.ConvTranspose1d)
+
+
+def run_fused(net: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Executes a CachedSequential fusing ``activation -> conv`` pairs into single kernel calls."""
+    mods = list(net)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        f = _act_of(m)
+        if f is not None and f[2] is None and i + 1 < len(mods) and isinstance(mods[i + 1], _CONV_TYPES):
+            x = mods[i + 1](x, act=f[0], slope=f[1])
+            i += 2
+            continue
+        x = m(x)
+        i += 1
+    return x
+
+
+def normalize_dilations(dilations: Union[Sequence[int], Sequence[Sequence[int]]], ratios: Sequence[int]):
+    if isinstance(dilations[0], int):
+        dilations = [dilations for _ in ratios]
+    return dilations
+
+
+class EncoderV2(nn.Module):
+    """rave/blocks.py:514-596."""
+
+    def __init__(self, data_size: Union[int, None], capacity: int, ratios: Sequence[int], latent_size: int,
+                 n_out: int, kernel_size: int, dilations: Sequence[int], keep_dim: bool = False,
+                 recurrent_layer: Optional[Callable[[], nn.Module]] = None, n_channels: int = 1,
+                 activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2),
+                 adain: Optional[Callable[[int], nn.Module]] = None, spectrogram=None) -> None:
+        super().__init__()
+        dilations_list = normalize_dilations(dilations, ratios)
+        data_size = data_size or n_channels
+        net = [normalization(cc.Conv1d(data_size * n_channels, capacity, kernel_size=kernel_size * 2 + 1,
+                                       padding=cc.get_padding(kernel_size * 2 + 1), bias=False))]
+        num_channels = capacity
+        for r, dils in zip(ratios, dilations_list):
+            for d in dils:
+                if adain is not None:
+                    net.append(adain(dim=num_channels))
+                net.append(Residual(DilatedUnit(dim=num_channels, kernel_size=kernel_size, dilation=d,
+                                                activation=activation)))
+            net.append(activation(num_channels))
+            out_channels = num_channels * r if keep_dim else num_channels * 2
+            net.append(normalization(cc.Conv1d(num_channels, out_channels, kernel_size=2 * r, stride=r,
+                                               padding=cc.get_padding(2 * r, r), bias=False)))
+            num_channels = out_channels
+        net.append(activation(num_channels))
+        net.append(normalization(cc.Conv1d(num_channels, latent_size * n_out, kernel_size=kernel_size,
+                                           padding=cc.get_padding(kernel_size), bias=False)))
+        if recurrent_layer is not None:
+            net.append(recurrent_layer(latent_size * n_out))
+        self.net = cc.CachedSequential(*net)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return run_fused(self.net, x)
+
+
+class GeneratorV2(nn.Module):
+    """rave/blocks.py:599-714 (noise_module=None path; NoiseGeneratorV2 is FFT work outside the
+    conv hot path and is not mirrored yet)."""
+
+    def __init__(self, capacity: int, ratios: Sequence[int], latent_size: int, kernel_size: int,
+                 dilations: Sequence[int], keep_dim: bool = False, data_size: Union[int, None] = None,
+                 recurrent_layer: Optional[Callable[[], nn.Module]] = None, n_channels: int = 1,
+                 amplitude_modulation: bool = False, noise_module=None,
+                 activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2),
+                 adain: Optional[Callable[[int], nn.Module]] = None) -> None:
+        super().__init__()
+        if noise_module is not None:
+            raise NotImplementedError("rave_amd.GeneratorV2: noise_module (v2_small) not mirrored yet")
+        data_size = n_channels if data_size is None else data_size * n_channels
+        dilations_list = normalize_dilations(dilations, ratios)[::-1]
+        ratios = ratios[::-1]
+        num_channels = int(np.prod(ratios)) * capacity if keep_dim else 2 ** len(ratios) * capacity
+        net = []
+        if recurrent_layer is not None:
+            net.append(recurrent_layer(latent_size))
+        net.append(normalization(cc.Conv1d(latent_size, num_channels, kernel_size=kernel_size,
+                                           padding=cc.get_padding(kernel_size), bias=False)))
+        for r, dils in zip(ratios, dilations_list):
+            out_channels = num_channels // r if keep_dim else num_channels // 2
+            net.append(activation(num_channels))
+            net.append(normalization(cc.ConvTranspose1d(num_channels, out_channels, 2 * r, stride=r,
+                                                        padding=r // 2, bias=False)))
+            num_channels = out_channels
+            for d in dils:
+                if adain is not None:
+                    net.append(adain(num_channels))
+                net.append(Residual(DilatedUnit(dim=num_channels, kernel_size=kernel_size, dilation=d,
+                                                activation=activation)))
+        net.append(activation(num_channels))
+        net.append(normalization(cc.Conv1d(num_channels, data_size * 2 if amplitude_modulation else data_size,
+                                           kernel_size=kernel_size * 2 + 1,
+                                           padding=cc.get_padding(kernel_size * 2 + 1), bias=False)))
+        self.noise_module = None
+        self.waveform_module = None
+        self.net = cc.CachedSequential(*net)
+        self.amplitude_modulation = amplitude_modulation
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = run_fused(self.net, x)
+        if self.amplitude_modulation:
+            return ops.amp_tanh(x)          # tanh(a * sigmoid(m)), rave/blocks.py:705-711
+        return torch.tanh(x)
+
+    def set_warmed_up(self, state: bool):
+        pass
+
+
+class VariationalEncoder(nn.Module):
+    """rave/blocks.py:717-745 (elementwise latent maths on a (B, 2*latent, 32) tensor: torch ops)."""
+
+    def __init__(self, encoder, beta: float = 1.0, n_channels=1):
+        super().__init__()
+        self.encoder = encoder(n_channels=n_channels)
+        self.beta = beta
+        self.register_buffer("warmed_up", torch.tensor(0))
+
+    def reparametrize(self, z, eps: Optional[torch.Tensor] = None):
+        mean, scale = z.chunk(2, 1)
+        std = nn.functional.softplus(scale) + 1e-4
+        var = std * std
+        logvar = torch.log(var)
+        noise = torch.randn_like(mean) if eps is None else eps
+        z = noise * std + mean
+        kl = (mean * mean + var - logvar - 1).sum(1).mean()
+        return z, self.beta * kl
+
+    def set_warmed_up(self, state: bool):
+        state = torch.tensor(int(state), device=self.warmed_up.device)
+        self.warmed_up = state
+
+    def forward(self, x: torch.Tensor):
+        z = self.encoder(x)
+        if self.warmed_up:
+            z = z.detach()
+        return z

@@ -1,0 +1,79 @@
+"""Builds librave_hip.so (gfx950) from rave_amd/csrc with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so travels to
+the GPU box with the repository snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "librave_hip.so")
+SOURCES = ["api.cpp", "pqmf.hip", "conv_igemm.hip", "conv_host.hip", "conv_wgrad.hip", "misc.hip"]
+HEADERS = ["common.hpp", "conv_params.hpp", os.path.join("..", "..", "include", "rave_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hip = _hipcc()
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s + ".o")
+        stamp = obj + ".sha"
+        dig = _digest([src] + hdrs)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        lang = ["-x", "hip"] if s.endswith(".hip") or s.endswith(".cpp") else []
+        jobs.append((s, [hip] + FLAGS + lang + ["-c", src, "-o", obj], stamp, dig))
+
+    def run(job):
+        name, cmd, stamp, dig = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {name}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        with open(stamp, "w") as f:
+            f.write(dig)
+        return name
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB) or force:
+        cmd = [hip, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,277 @@
+// Host side of the convolution entry points: geometry -> tap plan -> kernel parameters, weight
+// packing, and the extern "C" functions declared in include/rave_hip.h.
+#include "conv_params.hpp"
+
+int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const float* alpha,
+                 float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t stream);
+int64_t rh_wgrad_workspace(const rh_conv1d_desc* d);
+
+namespace {
+
+struct TapPlan {
+    int nphase = 0;
+    int oph[kMaxPhases], ntaps[kMaxPhases], tap0[kMaxPhases], minoff[kMaxPhases], maxoff[kMaxPhases];
+    int nslots = 0;
+    int kk[kMaxTaps], off[kMaxTaps];
+    int is = 1, os = 1;
+    int rows = 0;   // output rows per phase
+    int C = 0, M = 0;  // GEMM K-channels / GEMM rows
+    bool src_m_major = true;  // source index = (m*C + c)*k + kk, else (c*M + m)*k + kk
+};
+
+int validate(const rh_conv1d_desc* d) {
+    RH_REQUIRE(d, RH_ERR_INVALID, "conv1d: null descriptor");
+    RH_REQUIRE(d->batch >= 0 && d->c_in > 0 && d->c_out > 0 && d->l_in >= 0 && d->l_out >= 0,
+               RH_ERR_INVALID, "conv1d: bad sizes");
+    RH_REQUIRE(d->kernel >= 1 && d->stride >= 1 && d->dilation >= 1 && d->inner >= 1,
+               RH_ERR_INVALID, "conv1d: kernel/stride/dilation/inner must be >= 1");
+    RH_REQUIRE(d->groups == 1, RH_ERR_UNSUPPORTED, "conv1d: groups = %d not implemented", d->groups);
+    RH_REQUIRE(d->kernel <= kMaxTaps, RH_ERR_UNSUPPORTED, "conv1d: kernel %d > %d", d->kernel, kMaxTaps);
+    RH_REQUIRE(d->act >= RH_ACT_NONE && d->act <= RH_ACT_SNAKE, RH_ERR_INVALID, "conv1d: bad act");
+    RH_REQUIRE(d->in_valid >= 0 && d->in_valid <= (int64_t)d->l_in * d->inner, RH_ERR_INVALID,
+               "conv1d: in_valid out of range");
+    if (d->transposed) {
+        RH_REQUIRE(d->dilation == 1 && d->inner == 1, RH_ERR_UNSUPPORTED,
+                   "conv_transpose1d: dilation/inner must be 1");
+        RH_REQUIRE(d->stride <= kMaxPhases, RH_ERR_UNSUPPORTED, "conv_transpose1d: stride > %d", kMaxPhases);
+    } else if (d->stride > 1) {
+        RH_REQUIRE(d->stride <= kMaxPhases, RH_ERR_UNSUPPORTED, "conv1d: stride > %d", kMaxPhases);
+    }
+    return RH_OK;
+}
+
+// which: 0 = forward operand, 1 = data-gradient operand
+int build_plan(const rh_conv1d_desc* d, int which, TapPlan* tp) {
+    TapPlan& t = *tp;
+    const int k = d->kernel, s = d->stride, dil = d->dilation, P = d->pad_left;
+    auto phases = [&](int pad) {
+        t.nphase = s;
+        t.is = 1;
+        t.os = s;
+        for (int ph = 0; ph < s; ++ph) {
+            const int r0 = ((ph + pad) % s + s) % s;
+            const int base = (ph + pad - r0) / s;
+            t.oph[ph] = ph;
+            t.tap0[ph] = t.nslots;
+            int n = 0;
+            for (int m = 0; r0 + m * s < k; ++m, ++n) {
+                t.kk[t.nslots] = r0 + m * s;
+                t.off[t.nslots] = base - m;
+                ++t.nslots;
+            }
+            t.ntaps[ph] = n;
+        }
+    };
+    auto single = [&]() {
+        t.nphase = 1;
+        t.oph[0] = 0;
+        t.tap0[0] = 0;
+        t.ntaps[0] = k;
+        t.nslots = k;
+    };
+    if (which == 0) {
+        t.C = d->c_in;
+        t.M = d->c_out;
+        if (!d->transposed) {
+            single();
+            for (int i = 0; i < k; ++i) { t.kk[i] = i; t.off[i] = i * dil - P; }
+            t.is = s; t.os = 1; t.rows = d->l_out;
+            t.src_m_major = true;   // w[co=m][ci=c][kk]
+        } else {
+            phases(P);
+            t.rows = rh_cdiv(d->l_out, s);
+            t.src_m_major = false;  // w[ci=c][co=m][kk]
+        }
+    } else {
+        t.C = d->c_out;
+        t.M = d->c_in;
+        if (!d->transposed) {
+            if (s == 1) {
+                single();
+                for (int i = 0; i < k; ++i) { t.kk[i] = i; t.off[i] = P - i * dil; }
+                t.is = 1; t.os = 1; t.rows = d->l_in;
+            } else {
+                RH_REQUIRE(dil == 1, RH_ERR_UNSUPPORTED, "conv1d bwd_data: stride > 1 with dilation > 1");
+                phases(P);
+                t.rows = rh_cdiv(d->l_in, s);
+            }
+            t.src_m_major = false;  // w[co=c][ci=m][kk]
+        } else {
+            single();
+            for (int i = 0; i < k; ++i) { t.kk[i] = i; t.off[i] = i - P; }
+            t.is = s; t.os = 1; t.rows = d->l_in;
+            t.src_m_major = true;   // w[ci=m][co=c][kk]
+        }
+    }
+    for (int ph = 0; ph < t.nphase; ++ph) {
+        int lo = 0, hi = 0;
+        for (int i = 0; i < t.ntaps[ph]; ++i) {
+            const int o = t.off[t.tap0[ph] + i];
+            if (i == 0 || o < lo) lo = o;
+            if (i == 0 || o > hi) hi = o;
+        }
+        t.minoff[ph] = lo;
+        t.maxoff[ph] = hi;
+    }
+    return RH_OK;
+}
+
+inline int round32(int m) { return (m + 31) & ~31; }
+
+void plan_to_params(const TapPlan& t, ConvP* p) {
+    p->C = t.C;
+    p->M = t.M;
+    p->Mp = round32(t.M);
+    p->is = t.is;
+    p->os = t.os;
+    p->nphase = t.nphase;
+    long wofs = 0;
+    for (int ph = 0; ph < t.nphase; ++ph) {
+        p->ph_oph[ph] = t.oph[ph];
+        p->ph_ntaps[ph] = t.ntaps[ph];
+        p->ph_tap0[ph] = t.tap0[ph];
+        p->ph_minoff[ph] = t.minoff[ph];
+        p->ph_maxoff[ph] = t.maxoff[ph];
+        p->ph_wofs[ph] = wofs;
+        wofs += (long)t.ntaps[ph] * t.C * p->Mp;
+    }
+    for (int i = 0; i < t.nslots; ++i) p->off[i] = t.off[i];
+}
+
+struct PackP {
+    const float* w;
+    float* wp;
+    long total;  // nslots * C * Mp
+    int C, M, Mp, k;
+    int m_major;
+    int kk[kMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackP p) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.total) return;
+    const int m = (int)(e % p.Mp);
+    const long r = e / p.Mp;
+    const int c = (int)(r % p.C);
+    const int slot = (int)(r / p.C);
+    float v = 0.f;
+    if (m < p.M) {
+        const long src = p.m_major ? ((long)m * p.C + c) * p.k + p.kk[slot]
+                                   : ((long)c * p.M + m) * p.k + p.kk[slot];
+        v = p.w[src];
+    }
+    p.wp[e] = v;
+}
+
+int pack_one(const rh_conv1d_desc* d, int which, const float* w, float* wp, hipStream_t stream) {
+    TapPlan t;
+    if (int e = build_plan(d, which, &t)) return e;
+    PackP p{};
+    p.w = w; p.wp = wp; p.C = t.C; p.M = t.M; p.Mp = round32(t.M); p.k = d->kernel;
+    p.m_major = t.src_m_major ? 1 : 0;
+    p.total = (long)t.nslots * t.C * p.Mp;
+    for (int i = 0; i < t.nslots; ++i) p.kk[i] = t.kk[i];
+    if (p.total == 0) return RH_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)rh_cdiv64(p.total, 256)), dim3(256), 0, stream, p);
+    return rh_check_launch("conv1d_pack");
+}
+
+}  // namespace
+
+int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p) {
+    if (int e = validate(d)) return e;
+    TapPlan t;
+    if (int e = build_plan(d, 0, &t)) return e;
+    plan_to_params(t, p);
+    p->B = d->batch;
+    p->inner = d->inner;
+    const int in_full = d->l_in * d->inner;
+    p->in_valid = d->in_valid ? d->in_valid : in_full;
+    p->in_row = p->in_valid;          // memory row stride of x
+    p->out_row = d->l_out * d->inner;
+    p->out_valid = p->out_row;
+    p->ncols = t.rows * d->inner;
+    p->in_act = d->act;
+    p->in_slope = d->act_slope;
+    p->epi_act = RH_ACT_NONE;
+    p->epi_slope = 0.f;
+    return RH_OK;
+}
+
+int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p) {
+    if (int e = validate(d)) return e;
+    TapPlan t;
+    if (int e = build_plan(d, 1, &t)) return e;
+    plan_to_params(t, p);
+    p->B = d->batch;
+    p->inner = d->inner;
+    p->in_row = d->l_out * d->inner;  // dy rows
+    p->in_valid = p->in_row;
+    const int x_full = d->l_in * d->inner;
+    p->out_valid = d->in_valid ? d->in_valid : x_full;
+    p->out_row = p->out_valid;        // memory row stride of x / dx
+    p->ncols = t.rows * d->inner;
+    p->in_act = RH_ACT_NONE;
+    p->in_slope = 0.f;
+    p->epi_act = d->act;
+    p->epi_slope = d->act_slope;
+    return RH_OK;
+}
+
+extern "C" int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which) {
+    if (validate(d)) return -1;
+    const int64_t M = which == 0 ? d->c_out : d->c_in;
+    const int64_t C = which == 0 ? d->c_in : d->c_out;
+    return (int64_t)d->kernel * C * round32((int)M);
+}
+
+extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd,
+                                  float* wp_bwd, rh_stream_t stream) {
+    if (int e = validate(d)) return e;
+    RH_REQUIRE(w, RH_ERR_INVALID, "conv1d_pack: null weight");
+    if (wp_fwd)
+        if (int e = pack_one(d, 0, w, wp_fwd, (hipStream_t)stream)) return e;
+    if (wp_bwd)
+        if (int e = pack_one(d, 1, w, wp_bwd, (hipStream_t)stream)) return e;
+    return RH_OK;
+}
+
+extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_fwd,
+                                 const float* bias, const float* snake_alpha, const float* residual,
+                                 float* y, rh_stream_t stream) {
+    ConvP p{};
+    if (int e = rh_conv_fill_fwd(d, &p)) return e;
+    RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv1d_fwd: null pointer");
+    RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
+    p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
+    p.in_alpha = snake_alpha; p.mul_alpha = nullptr;
+    return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_fwd" : "conv1d_fwd");
+}
+
+extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd,
+                                      const float* x, const float* snake_alpha, const float* add,
+                                      float* dx, rh_stream_t stream) {
+    ConvP p{};
+    if (int e = rh_conv_fill_dgrad(d, &p)) return e;
+    RH_REQUIRE(dy && wp_bwd && dx, RH_ERR_INVALID, "conv1d_bwd_data: null pointer");
+    RH_REQUIRE(d->act == RH_ACT_NONE || x, RH_ERR_INVALID, "conv1d_bwd_data: act needs the forward input");
+    RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_data: snake needs alpha");
+    p.in = dy; p.wp = wp_bwd; p.out = dx; p.bias = nullptr; p.add = add;
+    p.mul_src = d->act == RH_ACT_NONE ? nullptr : x;
+    p.in_alpha = nullptr; p.mul_alpha = snake_alpha;
+    return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_bwd_data" : "conv1d_bwd_data");
+}
+
+extern "C" int64_t rh_conv1d_workspace_bytes(const rh_conv1d_desc* d) {
+    if (validate(d)) return -1;
+    return rh_wgrad_workspace(d);
+}
+
+extern "C" int rh_conv1d_bwd_weight_f32(const rh_conv1d_desc* d, const float* dy, const float* x,
+                                        const float* snake_alpha, float* dw, float* dbias,
+                                        void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    if (int e = validate(d)) return e;
+    RH_REQUIRE(dy && x && dw, RH_ERR_INVALID, "conv1d_bwd_weight: null pointer");
+    RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_weight: snake needs alpha");
+    return rh_wgrad_run(d, dy, x, snake_alpha, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
+}

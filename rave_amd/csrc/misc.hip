@@ -1,0 +1,173 @@
+// Small memory-bound kernels: weight normalisation, output head, activation, avg-pool.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // 256 threads; fixed-order tree -> deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// w[r,:] = g[r] * v[r,:] / ||v[r,:]||   (torch._weight_norm(v, g, 0); rave/blocks.py:15-22)
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                              long cols, float* __restrict__ w, float* __restrict__ norms) {
+    __shared__ float red[4];
+    const long r = blockIdx.x;
+    const float* vr = v + r * cols;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < cols; e += 256) { const float a = vr[e]; s += a * a; }
+    const float norm = sqrtf(block_sum(s, red));
+    const float scale = g[r] / norm;
+    float* wr = w + r * cols;
+    for (long e = threadIdx.x; e < cols; e += 256) wr[e] = vr[e] * scale;
+    if (threadIdx.x == 0 && norms) norms[r] = norm;
+}
+
+// dg[r] = <dw, v> / ||v|| ;  dv = (g/||v||) * (dw - v * <dw, v> / ||v||^2)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                              const float* __restrict__ g, const float* __restrict__ norms,
+                                                              long cols, float* __restrict__ dv, float* __restrict__ dg) {
+    __shared__ float red[4];
+    const long r = blockIdx.x;
+    const float* vr = v + r * cols;
+    const float* dwr = dw + r * cols;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < cols; e += 256) s += dwr[e] * vr[e];
+    const float dot = block_sum(s, red);
+    const float norm = norms[r];
+    const float scale = g[r] / norm;
+    const float coef = dot / (norm * norm);
+    float* dvr = dv + r * cols;
+    for (long e = threadIdx.x; e < cols; e += 256) dvr[e] = scale * (dwr[e] - vr[e] * coef);
+    if (threadIdx.x == 0) dg[r] = dot / norm;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// y = tanh(a * sigmoid(m)), x = [a | m] on the channel axis (rave/blocks.py:705-711)
+__global__ __launch_bounds__(256) void amp_tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long cl, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long b = e / cl, r = e - b * cl;
+    const float a = x[b * 2 * cl + r], m = x[b * 2 * cl + cl + r];
+    y[e] = tanhf(a * sigmoidf_(m));
+}
+__global__ __launch_bounds__(256) void amp_tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dx, long cl, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long b = e / cl, r = e - b * cl;
+    const float a = x[b * 2 * cl + r], m = x[b * 2 * cl + cl + r];
+    const float s = sigmoidf_(m);
+    const float t = tanhf(a * s);
+    const float gz = dy[e] * (1.f - t * t);
+    dx[b * 2 * cl + r] = gz * s;
+    dx[b * 2 * cl + cl + r] = gz * a * s * (1.f - s);
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                      int act, float slope, int c, long l, long total,
+                                                      float* __restrict__ y) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float al = 0.f;
+    if (act == RH_ACT_SNAKE) al = alpha[(e / l) % c];
+    y[e] = rh_act_apply(x[e], act, slope, al);
+}
+
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int l_in, int l_out, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long r = e / l_out;
+    const int i = (int)(e - r * l_out);
+    const float* src = x + r * l_in + 2 * i;
+    y[e] = (src[0] + src[1]) * 0.5f;
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                           int l_in, int l_out, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;  // over dx elements
+    if (e >= total) return;
+    const long r = e / l_in;
+    const int i = (int)(e - r * l_in);
+    const int o = i >> 1;
+    dx[e] = o < l_out ? dy[r * l_out + o] * 0.5f : 0.f;
+}
+
+inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int rh_weight_norm_fwd_f32(const float* v, const float* g, int64_t rows, int64_t cols, float* w,
+                                      float* norms, rh_stream_t stream) {
+    RH_REQUIRE(v && g && w, RH_ERR_INVALID, "weight_norm_fwd: null pointer");
+    RH_REQUIRE(rows >= 0 && cols > 0, RH_ERR_INVALID, "weight_norm_fwd: bad shape");
+    if (rows == 0) return RH_OK;
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, v, g,
+                       (long)cols, w, norms);
+    return rh_check_launch("weight_norm_fwd");
+}
+
+extern "C" int rh_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norms,
+                                      int64_t rows, int64_t cols, float* dv, float* dg, rh_stream_t stream) {
+    RH_REQUIRE(dw && v && g && norms && dv && dg, RH_ERR_INVALID, "weight_norm_bwd: null pointer");
+    RH_REQUIRE(rows >= 0 && cols > 0, RH_ERR_INVALID, "weight_norm_bwd: bad shape");
+    if (rows == 0) return RH_OK;
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dw, v, g,
+                       norms, (long)cols, dv, dg);
+    return rh_check_launch("weight_norm_bwd");
+}
+
+extern "C" int rh_amp_tanh_fwd_f32(const float* x, int32_t batch, int32_t c, int32_t l, float* y,
+                                   rh_stream_t stream) {
+    RH_REQUIRE(x && y, RH_ERR_INVALID, "amp_tanh_fwd: null pointer");
+    const long cl = (long)c * l, total = cl * batch;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(amp_tanh_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, cl, total);
+    return rh_check_launch("amp_tanh_fwd");
+}
+
+extern "C" int rh_amp_tanh_bwd_f32(const float* dy, const float* x, int32_t batch, int32_t c, int32_t l,
+                                   float* dx, rh_stream_t stream) {
+    RH_REQUIRE(dy && x && dx, RH_ERR_INVALID, "amp_tanh_bwd: null pointer");
+    const long cl = (long)c * l, total = cl * batch;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(amp_tanh_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, cl, total);
+    return rh_check_launch("amp_tanh_bwd");
+}
+
+extern "C" int rh_act_fwd_f32(const float* x, const float* snake_alpha, int32_t act, float slope,
+                              int32_t batch, int32_t c, int32_t l, float* y, rh_stream_t stream) {
+    RH_REQUIRE(x && y, RH_ERR_INVALID, "act_fwd: null pointer");
+    RH_REQUIRE(act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "act_fwd: snake needs alpha");
+    const long total = (long)batch * c * l;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, snake_alpha, act,
+                       slope, c, (long)l, total, y);
+    return rh_check_launch("act_fwd");
+}
+
+extern "C" int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream) {
+    RH_REQUIRE(x && y, RH_ERR_INVALID, "avgpool2_fwd: null pointer");
+    const int l_out = l_in / 2;
+    const long total = rows * l_out;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, l_in, l_out, total);
+    return rh_check_launch("avgpool2_fwd");
+}
+
+extern "C" int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream) {
+    RH_REQUIRE(dy && dx, RH_ERR_INVALID, "avgpool2_bwd: null pointer");
+    const int l_out = l_in / 2;
+    const long total = rows * l_in;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, l_in, l_out, total);
+    return rh_check_launch("avgpool2_bwd");
+}

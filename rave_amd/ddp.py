@@ -1,0 +1,143 @@
+"""Data-parallel gradient averaging for one process per GPU (RCCL over xGMI through
+``torch.distributed`` backend "nccl"; "gloo" on CPU for tests).
+
+The reference has no collective call of its own: multi-GPU training is Lightning's implicit DDP
+(scripts/train.py:242-255).  This is the MI355X-native equivalent for the hot
+path: clips are independent, so the only exchange is the gradient mean.
+
+* parameters are grouped into ~32 MiB buckets in REVERSE registration order (= the order their
+  gradients become final during backward: discriminator -> decoder -> encoder);
+* a post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its grads
+  are packed into one flat buffer and an asynchronous all-reduce is issued at once (RCCL runs it
+  on its own stream, overlapping the remaining backward kernels);
+* ``finish()`` (called between backward and optimizer.step) waits, averages and scatters back.
+  Buckets that did not complete (parameters without a gradient this step, e.g. the discriminator
+  in the VAE phase) are flushed with whatever gradients exist -- all ranks run the same phase, so
+  the pattern is identical everywhere.
+
+xGMI is point-to-point (7 links per GPU); a few large messages keep every link busy, hence the
+larger-than-NCCL-default bucket.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat: Optional[torch.Tensor] = None
+        self.pending = 0
+        self.ready: List[torch.nn.Parameter] = []
+        self.work = None
+        self.sent: List[torch.nn.Parameter] = []
+
+
+class GradReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
+                 process_group=None, overlap: bool = True):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        plist = [p for p in params if p.requires_grad]
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets: List[_Bucket] = []
+        cur: List[torch.nn.Parameter] = []
+        n = 0
+        for p in reversed(plist):
+            cur.append(p)
+            n += p.numel()
+            if n >= cap:
+                self.buckets.append(_Bucket(cur))
+                cur, n = [], 0
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._where = {}
+        self._hooks = []
+        for b in self.buckets:
+            for p in b.params:
+                self._where[p] = b
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.enabled = False
+        self.bytes_reduced = 0
+
+    # ---- lifecycle of one step
+    def begin(self) -> None:
+        """Call before backward."""
+        self.enabled = self.world > 1
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.ready = []
+            b.work = None
+            b.sent = []
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self.enabled:
+            return
+        b = self._where[p]
+        b.ready.append(p)
+        b.pending -= 1
+        if b.pending == 0 and self.overlap:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket) -> None:
+        ps = [p for p in b.ready if p.grad is not None]
+        if not ps:
+            return
+        n = sum(p.numel() for p in ps)
+        if b.flat is None or b.flat.numel() < b.numel or b.flat.device != ps[0].grad.device:
+            b.flat = torch.empty(b.numel, dtype=ps[0].grad.dtype, device=ps[0].grad.device)
+        flat = b.flat[:n]
+        views, o = [], 0
+        for p in ps:
+            views.append(flat[o:o + p.numel()].view_as(p.grad))
+            o += p.numel()
+        torch._foreach_copy_(views, [p.grad for p in ps])
+        b.sent = ps
+        b._views = views
+        b.work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.bytes_reduced += n * 4
+
+    def finish(self) -> None:
+        """Call after backward, before optimizer.step(): wait for the collectives and write the
+        averaged gradients back."""
+        if not self.enabled:
+            return
+        for b in self.buckets:
+            if b.work is None:
+                self._launch(b)      # incomplete bucket or overlap disabled
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            if b.work is None:
+                continue
+            b.work.wait()
+            torch._foreach_mul_(b._views, inv)
+            torch._foreach_copy_([p.grad for p in b.sent], b._views)
+            b.work = None
+        self.enabled = False
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, process_group=None) -> None:
+    """Rank-0 parameters AND buffers to every rank (what torch DDP does at construction and, for
+    buffers, before each forward: SURVEY.md section 2.3 C2)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=process_group)
+
+
+def shard_batch(global_batch: int, rank: int, world: int) -> int:
+    """Even split of the audio minibatch across ranks: 256 -> 32 per GPU."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
+    return global_batch // world

@@ -1,0 +1,76 @@
+"""Losses of RAVE.training_step (rave/core.py) -- NOT part of the HIP hot path.
+
+The multi-scale STFT distance runs on stock PyTorch-ROCm (torch.stft -> rocFFT); SURVEY.md section 8f
+ranks a fused STFT-loss kernel as the first "next" item.  Kept here only so that the bench can
+time the complete training step the metric is defined on.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+
+def mean_difference(target, value, norm: str = "L1", relative: bool = False):
+    """rave/core.py:236-252."""
+    diff = target - value
+    if norm == "L1":
+        diff = diff.abs().mean()
+        if relative:
+            diff = diff / target.abs().mean()
+        return diff
+    if norm == "L2":
+        diff = (diff * diff).mean()
+        if relative:
+            diff = diff / (target * target).mean()
+        return diff
+    raise Exception(f"Norm must be either L1 or L2, got {norm}")
+
+
+def hinge_gan(score_real, score_fake):
+    """rave/core.py:151-155."""
+    loss_dis = (torch.relu(1 - score_real) + torch.relu(1 + score_fake)).mean()
+    return loss_dis, -score_fake.mean()
+
+
+class MultiScaleSTFT(nn.Module):
+    """rave/core.py:269-319 with magnitude=True, no mel; torchaudio.transforms.Spectrogram(n_fft=s,
+    win_length=s, hop_length=s//4, power=None) == torch.stft(periodic Hann, center, reflect)."""
+
+    def __init__(self, scales: Sequence[int], sample_rate: int = 44100, magnitude: bool = True):
+        super().__init__()
+        if not magnitude:
+            raise NotImplementedError
+        self.scales = list(scales)
+        for s in self.scales:
+            self.register_buffer(f"window_{s}", torch.hann_window(s), persistent=False)
+
+    def forward(self, x):
+        x = x.reshape(-1, x.shape[-1])
+        out = []
+        for s in self.scales:
+            y = torch.stft(x, s, s // 4, s, window=getattr(self, f"window_{s}"), center=True,
+                           pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+            out.append(y.abs())
+        return out
+
+
+class AudioDistanceV1(nn.Module):
+    """rave/core.py:322-344."""
+
+    def __init__(self, multiscale_stft, log_epsilon: float) -> None:
+        super().__init__()
+        self.multiscale_stft = multiscale_stft()
+        self.log_epsilon = log_epsilon
+
+    def forward(self, x, y):
+        stfts_x = self.multiscale_stft(x)
+        stfts_y = self.multiscale_stft(y)
+        distance = 0.
+        for a, b in zip(stfts_x, stfts_y):
+            loga = torch.log(a + self.log_epsilon)
+            logb = torch.log(b + self.log_epsilon)
+            distance = distance + mean_difference(a, b, norm="L2", relative=True) \
+                + mean_difference(loga, logb, norm="L1")
+        return {"spectral_distance": distance}

@@ -1,0 +1,228 @@
+"""Stand-in for ``rave.model.RAVE`` (rave/model.py:133-424) used where the reference package
+cannot travel (the GPU box): same sub-module names (``pqmf``, ``encoder``, ``decoder``,
+``discriminator`` -> identical state_dict keys for the hot path) and a ``training_step`` that
+restates rave/model.py:288-413 statement by statement, driving the HIP drop-in modules.
+
+With the reference installed nothing here is needed: ``rave.model.RAVE`` itself runs on the
+drop-ins.  This file is host-side plumbing, not the product.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import blocks, cc, discriminator, losses, pqmf
+
+_default_loss_weights = {
+    "audio_distance": 1.,
+    "multiband_audio_distance": 1.,
+    "adversarial": 1.,
+    "feature_matching": 20,
+}
+
+
+def _pqmf_encode(pq, x: torch.Tensor):
+    """rave/model.py:116-122."""
+    batch_size = x.shape[:-2]
+    x_multiband = x.reshape(-1, 1, x.shape[-1])
+    x_multiband = pq(x_multiband)
+    return x_multiband.reshape(*batch_size, -1, x_multiband.shape[-1])
+
+
+def _pqmf_decode(pq, x: torch.Tensor, batch_size, n_channels: int):
+    """rave/model.py:125-130."""
+    x = x.reshape(x.shape[0] * n_channels, -1, x.shape[-1])
+    x = pq.inverse(x)
+    return x.reshape(*batch_size, n_channels, -1)
+
+
+class RAVE(nn.Module):
+    def __init__(self, latent_size, sampling_rate, encoder, decoder, discriminator, phase_1_duration,
+                 gan_loss, valid_signal_crop, feature_matching_fun, num_skipped_features,
+                 audio_distance: Callable[[], nn.Module], multiband_audio_distance: Callable[[], nn.Module],
+                 n_bands: int = 16, weights: Optional[Dict[str, float]] = None,
+                 pqmf: Optional[Callable[[], nn.Module]] = None, update_discriminator_every: int = 2,
+                 n_channels: int = 1):
+        super().__init__()
+        self.pqmf = pqmf(n_channels=n_channels)
+        self.encoder = encoder(n_channels=n_channels)
+        self.decoder = decoder(n_channels=n_channels)
+        self.discriminator = discriminator(n_channels=n_channels)
+        self.audio_distance = audio_distance()
+        self.multiband_audio_distance = multiband_audio_distance()
+        self.gan_loss = gan_loss
+        self.latent_size = latent_size
+        self.warmup = phase_1_duration
+        self.weights = dict(_default_loss_weights)
+        self.weights.update(weights or {})
+        self.warmed_up = False
+        self.sr = sampling_rate
+        self.valid_signal_crop = valid_signal_crop
+        self.n_channels = n_channels
+        self.feature_matching_fun = feature_matching_fun
+        self.num_skipped_features = num_skipped_features
+        self.update_discriminator_every = update_discriminator_every
+        self.beta_factor = 1.
+        self.register_buffer("receptive_field", torch.tensor([0, 0]).long())
+        self.logged: Dict[str, torch.Tensor] = {}
+        self._opts = None
+
+    # ---- rave/model.py:226-236
+    def configure_optimizers(self):
+        gen_p = list(self.encoder.parameters()) + list(self.decoder.parameters())
+        dis_p = list(self.discriminator.parameters())
+        gen_opt = torch.optim.Adam(gen_p, 1e-3, (.5, .9))
+        dis_opt = torch.optim.Adam(dis_p, 1e-4, (.5, .9))
+        self._opts = (gen_opt, dis_opt)
+        return gen_opt, dis_opt
+
+    def optimizers(self):
+        if self._opts is None:
+            self.configure_optimizers()
+        return self._opts
+
+    # ---- rave/model.py:244-270
+    def encode(self, x, return_mb: bool = False):
+        x_enc = _pqmf_encode(self.pqmf, x)
+        z = self.encoder(x_enc)
+        if return_mb:
+            return z, x_enc
+        return z
+
+    def decode(self, z):
+        batch_size = z.shape[:-2]
+        y = self.decoder(z)
+        return _pqmf_decode(self.pqmf, y, batch_size=batch_size, n_channels=self.n_channels)
+
+    def forward(self, x):
+        z = self.encode(x, return_mb=False)
+        z = self.encoder.reparametrize(z)[0]
+        return self.decode(z)
+
+    def split_features(self, features):
+        """rave/model.py:276-286."""
+        feature_real, feature_fake = [], []
+        for scale in features:
+            true, fake = zip(*map(lambda x: torch.split(x, x.shape[0] // 2, 0), scale))
+            feature_real.append(true)
+            feature_fake.append(fake)
+        return feature_real, feature_fake
+
+    # ---- rave/model.py:288-424
+    def training_step(self, batch, batch_idx, eps: Optional[torch.Tensor] = None, grad_sync=None):
+        """``eps`` injects the reparametrisation noise (parity runs); ``grad_sync(optimizer_index)``
+        is called between backward and optimizer.step (data-parallel gradient averaging)."""
+        gen_opt, dis_opt = self.optimizers()
+        x_raw = batch
+        x_raw.requires_grad = True
+        batch_size = x_raw.shape[:-2]
+        self.encoder.set_warmed_up(self.warmed_up)
+        self.decoder.set_warmed_up(self.warmed_up)
+
+        z, x_multiband = self.encode(x_raw, return_mb=True)
+        z, reg = self.encoder.reparametrize(z, eps)[:2]
+
+        y = self.decoder(z)
+        y_multiband = y
+        y_raw = _pqmf_decode(self.pqmf, y, batch_size=batch_size, n_channels=self.n_channels)
+        y_raw = y_raw[..., :x_raw.shape[-1]]
+        y_multiband = y_multiband[..., :x_multiband.shape[-1]]
+
+        if self.valid_signal_crop and self.receptive_field.sum():
+            raise NotImplementedError("valid_signal_crop with a measured receptive field")
+
+        distances = {}
+        multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
+        for k, v in multiband_distance.items():
+            distances[f"multiband_{k}"] = self.weights["multiband_audio_distance"] * v
+        fullband_distance = self.audio_distance(x_raw, y_raw)
+        for k, v in fullband_distance.items():
+            distances[f"fullband_{k}"] = self.weights["audio_distance"] * v
+
+        feature_matching_distance = 0.
+        if self.warmed_up:
+            xy = torch.cat([x_raw, y_raw], 0)
+            features = self.discriminator(xy)
+            feature_real, feature_fake = self.split_features(features)
+            loss_dis = 0
+            loss_adv = 0
+            for scale_real, scale_fake in zip(feature_real, feature_fake):
+                current = sum(map(self.feature_matching_fun,
+                                  scale_real[self.num_skipped_features:],
+                                  scale_fake[self.num_skipped_features:])) / len(scale_real[self.num_skipped_features:])
+                feature_matching_distance = feature_matching_distance + current
+                _dis, _adv = self.gan_loss(scale_real[-1], scale_fake[-1])
+                loss_dis = loss_dis + _dis
+                loss_adv = loss_adv + _adv
+            feature_matching_distance = feature_matching_distance / len(feature_real)
+        else:
+            loss_dis = torch.tensor(0.).to(x_raw)
+            loss_adv = torch.tensor(0.).to(x_raw)
+
+        loss_gen = {}
+        loss_gen.update(distances)
+        if reg.item():
+            loss_gen["regularization"] = reg * self.beta_factor
+        if self.warmed_up:
+            loss_gen["feature_matching"] = self.weights["feature_matching"] * feature_matching_distance
+            loss_gen["adversarial"] = self.weights["adversarial"] * loss_adv
+
+        if not (batch_idx % self.update_discriminator_every) and self.warmed_up:
+            dis_opt.zero_grad()
+            loss_dis.backward()
+            if grad_sync is not None:
+                grad_sync(1)
+            dis_opt.step()
+        else:
+            gen_opt.zero_grad()
+            loss_gen_value = 0.
+            for k, v in loss_gen.items():
+                loss_gen_value += v * self.weights.get(k, 1.)
+            loss_gen_value.backward()
+            if grad_sync is not None:
+                grad_sync(0)
+            gen_opt.step()
+
+        self.logged = dict(loss_gen)
+        self.logged["loss_dis"] = loss_dis
+        return self.logged
+
+
+V2_DILATIONS = [[1, 3, 9], [1, 3, 9], [1, 3, 9], [1, 3]]
+
+
+def build_v2(n_channels: int = 1, capacity: int = 96, ratios=(4, 4, 4, 2), latent_size: int = 128,
+             n_band: int = 16, dilations=None, sampling_rate: int = 44100, causal: bool = False,
+             disc_capacity: Optional[int] = None) -> RAVE:
+    """configs/v1.gin + configs/v2.gin transcribed (cf. oracle/ref_models.py for the citations)."""
+    cc.set_default_padding_mode("causal" if causal else "centered")
+    blocks.set_normalization_mode("weight_norm")
+    dil = dilations or V2_DILATIONS
+    ratios = list(ratios)
+    enc = partial(blocks.VariationalEncoder,
+                  encoder=partial(blocks.EncoderV2, data_size=n_band, capacity=capacity, ratios=ratios,
+                                  latent_size=latent_size, n_out=2, kernel_size=3, dilations=dil))
+    dec = partial(blocks.GeneratorV2, data_size=n_band, capacity=capacity, ratios=ratios,
+                  latent_size=latent_size, kernel_size=3, dilations=dil, amplitude_modulation=True)
+    common = dict(out_size=1, capacity=disc_capacity or capacity, n_layers=4, stride=4)
+    mpd = partial(discriminator.MultiPeriodDiscriminator, periods=[2, 3, 5, 7, 11],
+                  convnet=partial(discriminator.ConvNet, conv=nn.Conv2d, kernel_size=(5, 1), **common))
+    msd = partial(discriminator.MultiScaleDiscriminator, n_discriminators=3,
+                  convnet=partial(discriminator.ConvNet, conv=nn.Conv1d, kernel_size=15, **common))
+    disc = partial(discriminator.CombineDiscriminators, discriminators=[mpd, msd])
+    stft = partial(losses.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128], sample_rate=sampling_rate,
+                   magnitude=True)
+    dist = partial(losses.AudioDistanceV1, multiscale_stft=stft, log_epsilon=1e-7)
+    model = RAVE(latent_size=latent_size, sampling_rate=sampling_rate,
+                 pqmf=partial(pqmf.CachedPQMF, attenuation=100, n_band=n_band),
+                 encoder=enc, decoder=dec, discriminator=disc, phase_1_duration=1000000,
+                 gan_loss=losses.hinge_gan, valid_signal_crop=True,
+                 feature_matching_fun=partial(losses.mean_difference, norm="L1", relative=True),
+                 num_skipped_features=1, audio_distance=dist, multiband_audio_distance=dist,
+                 weights={"feature_matching": 20}, update_discriminator_every=4, n_channels=n_channels,
+                 n_bands=n_band)
+    cc.set_default_padding_mode("centered")
+    return model

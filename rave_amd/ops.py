@@ -1,0 +1,398 @@
+"""torch.autograd Functions over the C ABI (include/rave_hip.h).
+
+Every function requires contiguous fp32 CUDA(ROCm) tensors and enqueues on the current stream.
+There is no eager/PyTorch fallback: a missing library or a non-zero return code raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_SNAKE  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+# ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ------
+_PROFILE = None
+
+
+def profile_begin() -> None:
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """Returns [(kind, flops, bytes, milliseconds)] for every conv launch since profile_begin()."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    return [(k, f, b, e0.elapsed_time(e1)) for (k, f, b, e0, e1) in rec]
+
+
+def _conv_cost(d: "L.ConvDesc"):
+    """Algorithmic FLOPs and bytes of one conv launch (SURVEY.md section 8d rule: input once, output
+    once, weights once, fp32; activation / padding / residual count zero)."""
+    pos = d.l_in if d.transposed else d.l_out * d.inner
+    flops = 2.0 * d.batch * d.c_out * d.c_in * d.kernel * pos
+    x_elems = d.batch * d.c_in * (d.in_valid if d.in_valid else d.l_in * d.inner)
+    y_elems = d.batch * d.c_out * d.l_out * d.inner
+    w_elems = d.c_out * d.c_in * d.kernel
+    return flops, 4.0 * (x_elems + y_elems + w_elems)
+
+
+def _launch(kind: str, d, fn):
+    if _PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    f, b = _conv_cost(d)
+    _PROFILE.append((kind, f, b, e0, e1))
+    return r
+
+
+def _chk(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"rave_amd: {name} must live on the GPU (the HIP hot path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"rave_amd: {name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    """Static geometry of one convolution (see rh_conv1d_desc)."""
+    stride: int = 1
+    dilation: int = 1
+    pad_left: int = 0
+    pad_right: int = 0
+    transposed: bool = False
+    act: int = ACT_NONE
+    slope: float = 0.2
+    inner: int = 1          # W of a Conv2d with (k,1) kernel on (B,C,H,W)
+    fold: bool = False      # input is the un-folded (B,C,T) waveform of MultiPeriodDiscriminator
+
+    def out_len(self, l_in: int, k: int) -> int:
+        if self.transposed:
+            return (l_in - 1) * self.stride - 2 * self.pad_left + k
+        return (l_in + self.pad_left + self.pad_right - self.dilation * (k - 1) - 1) // self.stride + 1
+
+
+def _desc(g: ConvGeom, batch, c_in, c_out, l_in, l_out, k, in_valid=0) -> L.ConvDesc:
+    return L.ConvDesc(batch=batch, c_in=c_in, c_out=c_out, l_in=l_in, l_out=l_out, kernel=k,
+                      stride=g.stride, dilation=g.dilation, pad_left=g.pad_left,
+                      transposed=int(g.transposed), groups=1, inner=g.inner, in_valid=in_valid,
+                      act=g.act, act_slope=g.slope)
+
+
+def _shapes(x: Tensor, weight: Tensor, g: ConvGeom):
+    """Returns (batch, c_in, c_out, l_in, l_out, k, in_valid, out_shape)."""
+    k = weight.shape[2]
+    if g.transposed:
+        c_in, c_out = weight.shape[0], weight.shape[1]
+    else:
+        c_out, c_in = weight.shape[0], weight.shape[1]
+    b = x.shape[0]
+    if x.shape[1] != c_in:
+        raise RuntimeError(f"rave_amd conv: input has {x.shape[1]} channels, weight expects {c_in}")
+    in_valid = 0
+    if g.inner > 1:
+        if g.fold:  # (B, C, T) waveform, zero-padded to a multiple of `inner` in-kernel
+            t = x.shape[2]
+            l_in = -(-t // g.inner)
+            in_valid = t if l_in * g.inner != t else 0
+        else:       # (B, C, H, W)
+            if x.dim() != 4 or x.shape[3] != g.inner:
+                raise RuntimeError("rave_amd conv: expected (B, C, H, W) with W == inner")
+            l_in = x.shape[2]
+        l_out = g.out_len(l_in, k)
+        out_shape = (b, c_out, l_out, g.inner)
+    else:
+        l_in = x.shape[2]
+        l_out = g.out_len(l_in, k)
+        out_shape = (b, c_out, l_out)
+    return b, c_in, c_out, l_in, l_out, k, in_valid, out_shape
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = conv(act(x), w) + bias + residual   (rh_conv1d_fwd_f32 and its three gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, residual, g: ConvGeom):
+        x = _chk(x, "x"); weight = _chk(weight, "weight"); bias = _chk(bias, "bias")
+        alpha = _chk(alpha, "alpha"); residual = _chk(residual, "residual")
+        w3 = weight.reshape(weight.shape[0], weight.shape[1], -1) if weight.dim() == 4 else weight
+        b, c_in, c_out, l_in, l_out, k, in_valid, out_shape = _shapes(x, w3, g)
+        d = _desc(g, b, c_in, c_out, l_in, l_out, k, in_valid)
+        dref = C.byref(d)
+        need_dx = ctx.needs_input_grad[0]
+        wp_f = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 0), device=x.device, dtype=torch.float32)
+        wp_b = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 1), device=x.device,
+                           dtype=torch.float32) if need_dx else None
+        s = L.stream()
+        L.check(L.lib.rh_conv1d_pack_f32(dref, L.ptr(w3), L.ptr(wp_f), L.ptr(wp_b), s), "conv1d_pack")
+        y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+        if residual is not None and residual.shape != y.shape:
+            raise RuntimeError(f"rave_amd conv: residual shape {tuple(residual.shape)} != output {tuple(y.shape)}")
+        L.check(_launch("conv_fwd", d, lambda: L.lib.rh_conv1d_fwd_f32(
+            dref, L.ptr(x), L.ptr(wp_f), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), s)), "conv1d_fwd")
+        ctx.save_for_backward(x, wp_b, alpha)
+        ctx.d = d
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp_b, alpha = ctx.saved_tensors
+        d = ctx.d
+        dref = C.byref(d)
+        dy = _chk(dy, "dy")
+        s = L.stream()
+        dx = dw = db = dalpha = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(_launch("conv_dgrad", d, lambda: L.lib.rh_conv1d_bwd_data_f32(
+                dref, L.ptr(dy), L.ptr(wp_b), L.ptr(x), L.ptr(alpha), None, L.ptr(dx), s)), "conv1d_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
+            nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
+            ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
+            L.check(_launch("conv_wgrad", d, lambda: L.lib.rh_conv1d_bwd_weight_f32(
+                dref, L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes, s)), "conv1d_bwd_weight")
+        if alpha is not None and ctx.needs_input_grad[3]:
+            raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.ops.snake + conv")
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = dy
+        return dx, dw, db, dalpha, dres, None
+
+
+def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, geom: ConvGeom,
+           alpha: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
+    return _ConvFn.apply(x, weight, bias, alpha, residual, geom)
+
+
+class _WeightNormFn(torch.autograd.Function):
+    """w = g * v / ||v|| over dims != 0 (rh_weight_norm_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v = _chk(v, "weight_v"); g = _chk(g, "weight_g")
+        rows = v.shape[0]
+        cols = v.numel() // max(rows, 1)
+        w = torch.empty_like(v)
+        norms = torch.empty(rows, device=v.device, dtype=torch.float32)
+        L.check(L.lib.rh_weight_norm_fwd_f32(L.ptr(v), L.ptr(g), rows, cols, L.ptr(w), L.ptr(norms), L.stream()),
+                "weight_norm_fwd")
+        ctx.save_for_backward(v, g, norms)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g, norms = ctx.saved_tensors
+        dw = _chk(dw, "dw")
+        rows = v.shape[0]
+        cols = v.numel() // max(rows, 1)
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        L.check(L.lib.rh_weight_norm_bwd_f32(L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(norms), rows, cols,
+                                             L.ptr(dv), L.ptr(dg), L.stream()), "weight_norm_bwd")
+        return dv, dg
+
+
+def weight_norm(v: Tensor, g: Tensor) -> Tensor:
+    return _WeightNormFn.apply(v, g)
+
+
+class _ResidualUnitFn(torch.autograd.Function):
+    """Residual(DilatedUnit) as ONE autograd node (rave/blocks.py:31-45, 83-112):
+        h = conv_k3_dil(act(x), w3);  y = conv_k1(act(h), w1) + x
+    Saves only x and h; activations, padding and the residual add live inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w3, w1, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom):
+        x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1")
+        alpha0 = _chk(alpha0, "alpha0"); alpha2 = _chk(alpha2, "alpha2")
+        b, c, l = x.shape
+        k = w3.shape[2]
+        d3 = _desc(g3, b, c, c, l, l, k)
+        d1 = _desc(g1, b, c, c, l, l, 1)
+        r3, r1 = C.byref(d3), C.byref(d1)
+        s = L.stream()
+        dev = x.device
+        n3 = L.lib.rh_conv1d_packed_floats(r3, 0)
+        n1 = L.lib.rh_conv1d_packed_floats(r1, 0)
+        wp3f = torch.empty(n3, device=dev); wp3b = torch.empty(L.lib.rh_conv1d_packed_floats(r3, 1), device=dev)
+        wp1f = torch.empty(n1, device=dev); wp1b = torch.empty(L.lib.rh_conv1d_packed_floats(r1, 1), device=dev)
+        L.check(L.lib.rh_conv1d_pack_f32(r3, L.ptr(w3), L.ptr(wp3f), L.ptr(wp3b), s), "pack")
+        L.check(L.lib.rh_conv1d_pack_f32(r1, L.ptr(w1), L.ptr(wp1f), L.ptr(wp1b), s), "pack")
+        h = torch.empty_like(x)
+        y = torch.empty_like(x)
+        L.check(_launch("conv_fwd", d3, lambda: L.lib.rh_conv1d_fwd_f32(
+            r3, L.ptr(x), L.ptr(wp3f), None, L.ptr(alpha0), None, L.ptr(h), s)), "unit k3")
+        L.check(_launch("conv_fwd", d1, lambda: L.lib.rh_conv1d_fwd_f32(
+            r1, L.ptr(h), L.ptr(wp1f), None, L.ptr(alpha2), L.ptr(x), L.ptr(y), s)), "unit k1")
+        ctx.save_for_backward(x, h, wp3b, wp1b, alpha0, alpha2)
+        ctx.d3, ctx.d1 = d3, d1
+        ctx.w3shape, ctx.w1shape = tuple(w3.shape), tuple(w1.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, wp3b, wp1b, alpha0, alpha2 = ctx.saved_tensors
+        d3, d1 = ctx.d3, ctx.d1
+        r3, r1 = C.byref(d3), C.byref(d1)
+        dy = _chk(dy, "dy")
+        s = L.stream()
+        dev = dy.device
+        if (alpha0 is not None and ctx.needs_input_grad[3]) or (alpha2 is not None and ctx.needs_input_grad[4]):
+            raise NotImplementedError("rave_amd: Snake alpha gradient in the fused residual unit")
+        dh = torch.empty_like(h)
+        L.check(_launch("conv_dgrad", d1, lambda: L.lib.rh_conv1d_bwd_data_f32(
+            r1, L.ptr(dy), L.ptr(wp1b), L.ptr(h), L.ptr(alpha2), None, L.ptr(dh), s)), "unit k1 dgrad")
+        dw1 = dw3 = dx = None
+        n1 = L.lib.rh_conv1d_workspace_bytes(r1)
+        n3 = L.lib.rh_conv1d_workspace_bytes(r3)
+        ws = torch.empty(max(n1, n3, 4) // 4, device=dev)
+        if ctx.needs_input_grad[2]:
+            dw1 = torch.empty(ctx.w1shape, device=dev)
+            L.check(_launch("conv_wgrad", d1, lambda: L.lib.rh_conv1d_bwd_weight_f32(
+                r1, L.ptr(dy), L.ptr(h), L.ptr(alpha2), L.ptr(dw1), None, L.ptr(ws), n1, s)), "unit k1 wgrad")
+        if ctx.needs_input_grad[1]:
+            dw3 = torch.empty(ctx.w3shape, device=dev)
+            L.check(_launch("conv_wgrad", d3, lambda: L.lib.rh_conv1d_bwd_weight_f32(
+                r3, L.ptr(dh), L.ptr(x), L.ptr(alpha0), L.ptr(dw3), None, L.ptr(ws), n3, s)), "unit k3 wgrad")
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dx = act'(x) * dgrad_k3(dh) + dy   (residual gradient fused as `add`)
+            L.check(_launch("conv_dgrad", d3, lambda: L.lib.rh_conv1d_bwd_data_f32(
+                r3, L.ptr(dh), L.ptr(wp3b), L.ptr(x), L.ptr(alpha0), L.ptr(dy), L.ptr(dx), s)), "unit k3 dgrad")
+        return dx, dw3, dw1, None, None, None, None
+
+
+def residual_unit(x, w3, w1, g3: ConvGeom, g1: ConvGeom, alpha0=None, alpha2=None) -> Tensor:
+    return _ResidualUnitFn.apply(x, w3, w1, alpha0, alpha2, g3, g1)
+
+
+# --------------------------------------------------------------------------- PQMF
+class _PqmfAnalysisFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, pad: Tuple[int, int]):
+        x = _chk(x, "x"); w = _chk(w, "forward_conv.weight")
+        rows, one, t = x.shape
+        if one != 1:
+            raise RuntimeError("pqmf analysis expects (B*C, 1, T)")
+        m, _, k = w.shape
+        n_frames = (t + pad[0] + pad[1] - k) // m + 1
+        y = torch.empty(rows, m, n_frames, device=x.device, dtype=torch.float32)
+        L.check(L.lib.rh_pqmf_analysis_fwd_f32(L.ptr(x), L.ptr(w), rows, t, m, k, pad[0], n_frames, L.ptr(y), L.stream()),
+                "pqmf_analysis_fwd")
+        ctx.save_for_backward(w)
+        ctx.geo = (rows, t, m, k, pad[0], n_frames)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        rows, t, m, k, pl, n_frames = ctx.geo
+        dy = _chk(dy, "dy")
+        dx = torch.empty(rows, 1, t, device=dy.device, dtype=torch.float32)
+        L.check(L.lib.rh_pqmf_analysis_bwd_f32(L.ptr(dy), L.ptr(w), rows, t, m, k, pl, n_frames, L.ptr(dx), L.stream()),
+                "pqmf_analysis_bwd")
+        return dx, None, None
+
+
+class _PqmfSynthesisFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, w, pad: Tuple[int, int]):
+        y = _chk(y, "y"); w = _chk(w, "inverse_conv.weight")
+        rows, m, n_frames = y.shape
+        k = w.shape[2]
+        n_out = n_frames + pad[0] + pad[1] - k + 1
+        x = torch.empty(rows, 1, n_out * m, device=y.device, dtype=torch.float32)
+        L.check(L.lib.rh_pqmf_synthesis_fwd_f32(L.ptr(y), L.ptr(w), rows, n_frames, m, k, pad[0], n_out, L.ptr(x), L.stream()),
+                "pqmf_synthesis_fwd")
+        ctx.save_for_backward(w)
+        ctx.geo = (rows, n_frames, m, k, pad[0], n_out)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (w,) = ctx.saved_tensors
+        rows, n_frames, m, k, pl, n_out = ctx.geo
+        dx = _chk(dx, "dx")
+        dy = torch.empty(rows, m, n_frames, device=dx.device, dtype=torch.float32)
+        L.check(L.lib.rh_pqmf_synthesis_bwd_f32(L.ptr(dx), L.ptr(w), rows, n_frames, m, k, pl, n_out, L.ptr(dy), L.stream()),
+                "pqmf_synthesis_bwd")
+        return dy, None, None
+
+
+def pqmf_analysis(x: Tensor, w: Tensor, pad: Tuple[int, int]) -> Tensor:
+    return _PqmfAnalysisFn.apply(x, w, pad)
+
+
+def pqmf_synthesis(y: Tensor, w: Tensor, pad: Tuple[int, int]) -> Tensor:
+    return _PqmfSynthesisFn.apply(y, w, pad)
+
+
+# --------------------------------------------------------------------------- small ops
+class _AmpTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        b, c2, l = x.shape
+        y = torch.empty(b, c2 // 2, l, device=x.device, dtype=torch.float32)
+        L.check(L.lib.rh_amp_tanh_fwd_f32(L.ptr(x), b, c2 // 2, l, L.ptr(y), L.stream()), "amp_tanh_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        b, c2, l = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.lib.rh_amp_tanh_bwd_f32(L.ptr(dy), L.ptr(x), b, c2 // 2, l, L.ptr(dx), L.stream()), "amp_tanh_bwd")
+        return dx
+
+
+def amp_tanh(x: Tensor) -> Tensor:
+    """tanh(a * sigmoid(m)) with [a | m] = x.split(C/2, 1)  (rave/blocks.py:705-711)."""
+    return _AmpTanhFn.apply(x)
+
+
+class _AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "x")
+        l_in = x.shape[-1]
+        rows = x.numel() // max(l_in, 1)
+        y = torch.empty(*x.shape[:-1], l_in // 2, device=x.device, dtype=torch.float32)
+        L.check(L.lib.rh_avgpool2_fwd_f32(L.ptr(x), rows, l_in, L.ptr(y), L.stream()), "avgpool2_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _chk(dy, "dy")
+        l_in = ctx.shape[-1]
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        rows = dx.numel() // max(l_in, 1)
+        L.check(L.lib.rh_avgpool2_bwd_f32(L.ptr(dy), rows, l_in, L.ptr(dx), L.stream()), "avgpool2_bwd")
+        return dx
+
+
+def avg_pool2(x: Tensor) -> Tensor:
+    return _AvgPool2Fn.apply(x)

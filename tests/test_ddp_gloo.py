@@ -1,0 +1,82 @@
+"""world_size-2 gloo test (CPU) of the data-parallel gradient reducer (rave_amd/ddp.py): bucketed
+all-reduce launched from post-accumulate-grad hooks must equal the full-batch gradient."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_net():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Conv1d(4, 8, 3, padding=1), nn.LeakyReLU(0.2), nn.Conv1d(8, 8, 3, padding=1),
+                         nn.LeakyReLU(0.2), nn.Conv1d(8, 2, 1))
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rave_amd.ddp import GradReducer, broadcast_module, shard_batch
+    net = _make_net()
+    if rank == 1:  # perturb rank 1, broadcast must restore rank-0 weights
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    broadcast_module(net)
+    extra = nn.Parameter(torch.zeros(3))          # a parameter that never receives a gradient
+    red = GradReducer(list(net.parameters()) + [extra], bucket_mb=0.0005, overlap=overlap)
+    assert len(red.buckets) > 1
+    torch.manual_seed(1)
+    x = torch.randn(8, 4, 32)
+    per = shard_batch(8, rank, world)
+    xs = x[rank * per:(rank + 1) * per]
+    for step in range(2):
+        net.zero_grad()
+        red.begin()
+        loss = net(xs).pow(2).mean()
+        loss.backward()
+        red.finish()
+    q.put((rank, [p.grad.clone() for p in net.parameters()], extra.grad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    net = _make_net()
+    torch.manual_seed(1)
+    x = torch.randn(8, 4, 32)
+    # mean over ranks of per-shard mean losses == full-batch mean loss (equal shards)
+    net(x).pow(2).mean().backward()
+    for rank, grads, extra in out:
+        assert extra is None
+        for g, p in zip(grads, net.parameters()):
+            assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_grad_reducer_overlapped():
+    _run(True)
+
+
+def test_grad_reducer_flush_only():
+    _run(False)

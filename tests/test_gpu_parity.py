@@ -1,0 +1,397 @@
+"""GPU parity tests (run with ``-m gpu`` on a MI355X): the HIP path, called through the C ABI via
+rave_amd's ctypes binding, against (a) the oracle (oracle/rave_oracle.py, CPU fp32 ATen) on the same
+seeded inputs, (b) the committed golden fixtures produced by the unmodified reference, and
+(c) size-independent properties at BASELINE sizes.
+
+Tolerance (BASELINE.json north_star): <= 1e-4 relative L2 vs the reference; the exact-f32 MFMA
+kernels are expected at ~1e-6 per module, and the PQMF band/sign indexing must be bit-exact.
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rave_oracle as O
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 2e-5      # single operator vs CPU fp32
+TOL_E2E = 1e-4     # north_star end-to-end tolerance
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rave_amd import ops as _ops
+    return _ops
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+# --------------------------------------------------------------------------- PQMF
+def test_pqmf_golden_fwd_inv_and_grads(golden_dir, dev, ops):
+    g = _load(golden_dir, "pqmf.pt")
+    wf, wi = g["w_fwd"].to(dev), g["w_inv"].to(dev)
+    x = g["x"].reshape(-1, 1, g["x"].shape[-1]).to(dev).requires_grad_(True)
+    y = ops.pqmf_analysis(x, wf, (256, 256))
+    assert y.shape == g["y"].shape
+    assert rel_l2(y, g["y"]) < TOL_OP
+    # band / sign indexing must be exact: the sign of every non-negligible coefficient agrees
+    big = g["y"].abs() > 1e-4
+    assert torch.equal(torch.sign(y.detach().cpu())[big], torch.sign(g["y"])[big])
+    (y * g["cot_y"].to(dev)).sum().backward()
+    assert rel_l2(x.grad, g["grad_x"]) < TOL_OP
+    yy = g["y"].to(dev).requires_grad_(True)
+    xr = ops.pqmf_synthesis(yy, wi, (16, 16))
+    assert xr.shape == g["x_rec"].shape
+    assert rel_l2(xr, g["x_rec"]) < TOL_OP
+    (xr * g["cot_x"].to(dev)).sum().backward()
+    assert rel_l2(yy.grad, g["grad_y"]) < TOL_OP
+    # causal overlay: pads (512, 0) and (32, 0)
+    with torch.no_grad():
+        yc = ops.pqmf_analysis(x.detach(), wf, (512, 0))
+        assert rel_l2(yc, g["y_causal"]) < TOL_OP
+        xc = ops.pqmf_synthesis(g["y_causal"].to(dev), wi, (32, 0))
+        assert rel_l2(xc, g["x_rec_causal"]) < TOL_OP
+
+
+def test_pqmf_reverse_half_is_bit_exact(dev, ops):
+    """A filter that is a pure delta makes analysis a decimating copy: the output must then equal
+    +-x exactly, with the reverse_half pattern (odd band AND even frame -> minus)."""
+    w = torch.zeros(16, 1, 513)
+    for k in range(16):
+        w[k, 0, 256 + k] = 1.0          # band k picks sample 16 n + k
+    x = torch.randn(2, 1, 1024)
+    y = ops.pqmf_analysis(x.to(dev), w.to(dev), (256, 256)).cpu()
+    ref = x.reshape(2, 64, 16).permute(0, 2, 1).clone()
+    ref[:, 1::2, ::2] *= -1
+    assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("t_len", [16, 48, 4096 + 16, 65536])
+def test_pqmf_vs_oracle_sizes(dev, ops, t_len):
+    b = O.pqmf_buffers(100, 16)
+    wf, wi = b["forward_conv.weight"], b["inverse_conv.weight"]
+    rows = 3 if t_len < 65536 else 2
+    x = O.synthetic_batch(rows, 1, t_len, seed=t_len)
+    y_ref = O.pqmf_analysis(x, wf)
+    y = ops.pqmf_analysis(x.to(dev), wf.to(dev), (256, 256))
+    assert y.shape == y_ref.shape
+    assert rel_l2(y, y_ref) < TOL_OP
+    xr_ref = O.pqmf_synthesis(y_ref, wi)
+    xr = ops.pqmf_synthesis(y_ref.to(dev), wi.to(dev), (16, 16))
+    assert xr.shape == xr_ref.shape
+    assert rel_l2(xr, xr_ref) < TOL_OP
+
+
+def test_pqmf_full_size_properties(dev, ops):
+    """BASELINE size 32 x 65536: linearity, near-perfect reconstruction (delay 16), empty batch."""
+    b = O.pqmf_buffers(100, 16)
+    wf, wi = b["forward_conv.weight"].to(dev), b["inverse_conv.weight"].to(dev)
+    x1 = O.synthetic_batch(32, 1, 65536, seed=1).to(dev)
+    x2 = O.synthetic_batch(32, 1, 65536, seed=2).to(dev)
+    y1 = ops.pqmf_analysis(x1, wf, (256, 256))
+    y2 = ops.pqmf_analysis(x2, wf, (256, 256))
+    y12 = ops.pqmf_analysis(x1 + 0.5 * x2, wf, (256, 256))
+    assert rel_l2(y12, y1 + 0.5 * y2) < 1e-5
+    xr = ops.pqmf_synthesis(y1, wi, (16, 16))
+    assert rel_l2(xr[..., 2048 + 16:-2048], x1[..., 2048:-2048 - 16]) < 5e-3
+    # adjointness <A x, c> == <x, A^T c>
+    xa = x1.clone().requires_grad_(True)
+    c = torch.randn_like(y1)
+    ya = ops.pqmf_analysis(xa, wf, (256, 256))
+    (ya * c).sum().backward()
+    lhs = float((ya.detach().double() * c.double()).sum())
+    rhs = float((xa.grad.double() * x1.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+    e = ops.pqmf_analysis(torch.zeros(0, 1, 4096, device=dev), wf, (256, 256))
+    assert e.shape == (0, 16, 256)
+
+
+# --------------------------------------------------------------------------- conv1d
+def _ref_conv(x, w, b, stride, dil, pad, act, slope, alpha, residual):
+    xa = x
+    if act == 1:
+        xa = F.leaky_relu(x, slope)
+    elif act == 2:
+        xa = x + (alpha + 1e-9).reciprocal() * (alpha * x).sin().pow(2)
+    y = O.cc_conv1d(xa, w, b, stride, dil, pad)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, L, k, stride, dil, pad, act, bias, residual)
+    (2, 16, 96, 300, 7, 1, 1, (3, 3), 0, False, False),     # stem
+    (2, 96, 96, 257, 3, 1, 9, (9, 9), 1, False, False),     # dilated k3
+    (3, 96, 96, 128, 1, 1, 1, (0, 0), 1, False, True),      # pointwise + residual
+    (2, 96, 192, 512, 8, 4, 1, (3, 4), 1, False, False),    # down x4 (centered pad of cc.get_padding(8))
+    (2, 48, 96, 100, 4, 2, 1, (1, 2), 1, False, False),     # down x2, Cin not multiple of 32
+    (5, 768, 256, 32, 3, 1, 1, (1, 1), 1, False, False),    # short sequence, batch folded into N
+    (2, 96, 32, 700, 7, 1, 1, (6, 0), 1, False, False),     # causal pad, small Cout
+    (2, 6, 12, 70, 3, 1, 3, (3, 3), 1, True, True),         # tiny ragged channels, bias
+    (4, 1, 96, 1000, 15, 4, 1, (7, 7), 0, True, False),     # MSD first layer (Cin = 1)
+    (4, 96, 1, 64, 1, 1, 1, (0, 0), 1, True, False),        # MSD last layer (Cout = 1)
+    (1, 130, 70, 33, 5, 1, 2, (4, 4), 0, False, False),     # odd sizes everywhere
+    (2, 32, 32, 5, 3, 1, 1, (1, 1), 2, False, False),       # snake, sequence shorter than a tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d_fwd_and_grads_vs_cpu(dev, ops, case):
+    B, Ci, Co, L, k, s, d, pad, act, has_b, has_r = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / math.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g) if has_b else None
+    alpha = (torch.rand(Ci, 1, generator=g) + 0.5) if act == 2 else None
+    geom = ops.ConvGeom(stride=s, dilation=d, pad_left=pad[0], pad_right=pad[1], act=act, slope=0.2)
+    l_out = geom.out_len(L, k)
+    r = torch.randn(B, Co, l_out, generator=g) if has_r else None
+    cot = torch.randn(B, Co, l_out, generator=g)
+
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_b else None
+    y_ref = _ref_conv(xr, wr, br, s, d, pad, act, 0.2, alpha, r)
+    (y_ref * cot).sum().backward()
+
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if has_b else None
+    y = ops.conv1d(xg, wg, bg, geom=geom, alpha=None if alpha is None else alpha.reshape(-1).to(dev),
+                   residual=None if r is None else r.to(dev))
+    assert y.shape == y_ref.shape
+    assert rel_l2(y, y_ref) < TOL_OP
+    (y * cot.to(dev)).sum().backward()
+    assert rel_l2(xg.grad, xr.grad) < TOL_OP
+    assert rel_l2(wg.grad, wr.grad) < TOL_OP
+    if has_b:
+        assert rel_l2(bg.grad, br.grad) < TOL_OP
+
+
+CONVT_CASES = [
+    # (B, Cin, Cout, L, k, stride, pad, act)
+    (2, 192, 96, 64, 8, 4, 2, 1),
+    (3, 1536 // 8, 768 // 8, 32, 4, 2, 1, 1),
+    (2, 40, 24, 17, 4, 2, 1, 0),
+    (1, 64, 32, 9, 16, 8, 4, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose1d_vs_cpu(dev, ops, case):
+    B, Ci, Co, L, k, s, p, act = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Ci, L, generator=g)
+    w = torch.randn(Ci, Co, k, generator=g) / math.sqrt(Ci * k / s)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xa = F.leaky_relu(xr, 0.2) if act else xr
+    y_ref = F.conv_transpose1d(xa, wr, None, s, p)
+    cot = torch.randn(y_ref.shape, generator=g)
+    (y_ref * cot).sum().backward()
+    geom = ops.ConvGeom(stride=s, pad_left=p, pad_right=p, transposed=True, act=act, slope=0.2)
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = ops.conv1d(xg, wg, None, geom=geom)
+    assert y.shape == y_ref.shape
+    assert rel_l2(y, y_ref) < TOL_OP
+    (y * cot.to(dev)).sum().backward()
+    assert rel_l2(xg.grad, xr.grad) < TOL_OP
+    assert rel_l2(wg.grad, wr.grad) < TOL_OP
+
+
+@pytest.mark.parametrize("period,T,Ci,Co,act", [(2, 1000, 1, 24, 0), (3, 1000, 1, 24, 0), (11, 997, 1, 40, 0),
+                                                (5, 50, 24, 48, 1), (7, 21, 96, 1, 1)])
+def test_conv2d_k1_period_fold_vs_cpu(dev, ops, period, T, Ci, Co, act):
+    """MultiPeriodDiscriminator layer: fold (zero pad + reshape) -> Conv2d (5,1) s(4,1) p(2,0)."""
+    g = torch.Generator().manual_seed(period * 1000 + T)
+    first = Ci == 1
+    k, s, p = (5, 4, 2) if Co != 1 else (1, 1, 0)
+    if first:
+        x = torch.randn(3, Ci, T, generator=g)
+    else:
+        x = torch.randn(3, Ci, T, period, generator=g)
+    w = torch.randn(Co, Ci, k, 1, generator=g) / math.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    if first:
+        padn = (period - (T % period)) % period
+        xf = F.pad(xr, (0, padn)).reshape(3, Ci, -1, period)
+    else:
+        xf = xr
+    xa = F.leaky_relu(xf, 0.2) if act else xf
+    y_ref = F.conv2d(xa, wr, br, (s, 1), (p, 0))
+    cot = torch.randn(y_ref.shape, generator=g)
+    (y_ref * cot).sum().backward()
+    geom = ops.ConvGeom(stride=s, pad_left=p, pad_right=p, act=act, slope=0.2, inner=period, fold=first)
+    xg, wg, bg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.conv1d(xg, wg, bg, geom=geom)
+    assert y.shape == y_ref.shape
+    assert rel_l2(y, y_ref) < TOL_OP
+    (y * cot.to(dev)).sum().backward()
+    assert rel_l2(xg.grad, xr.grad) < TOL_OP
+    assert rel_l2(wg.grad, wr.grad) < TOL_OP
+    assert rel_l2(bg.grad, br.grad) < TOL_OP
+
+
+def test_weight_norm_fwd_bwd(dev, ops):
+    for shape in [(96, 16, 7), (1536, 768, 4), (24, 1, 5, 1), (7, 3, 1)]:
+        v = torch.randn(*shape)
+        g = torch.rand(shape[0], *([1] * (len(shape) - 1))) + 0.5
+        vr, gr = v.clone().requires_grad_(True), g.clone().requires_grad_(True)
+        w_ref = torch._weight_norm(vr, gr, 0)
+        cot = torch.randn(*shape)
+        (w_ref * cot).sum().backward()
+        vg, gg = v.to(dev).requires_grad_(True), g.to(dev).requires_grad_(True)
+        w = ops.weight_norm(vg, gg)
+        assert rel_l2(w, w_ref) < 1e-6
+        (w * cot.to(dev)).sum().backward()
+        assert rel_l2(vg.grad, vr.grad) < 1e-5
+        assert rel_l2(gg.grad, gr.grad) < 1e-5
+
+
+def test_amp_tanh_and_avgpool(dev, ops):
+    x = torch.randn(3, 32, 100)
+    xr = x.clone().requires_grad_(True)
+    a, m = xr.split(16, 1)
+    y_ref = torch.tanh(a * torch.sigmoid(m))
+    cot = torch.randn_like(y_ref)
+    (y_ref * cot).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    y = ops.amp_tanh(xg)
+    assert rel_l2(y, y_ref) < 1e-6
+    (y * cot.to(dev)).sum().backward()
+    assert rel_l2(xg.grad, xr.grad) < 1e-5
+    for L in (100, 101):
+        x = torch.randn(4, 1, L)
+        xr = x.clone().requires_grad_(True)
+        y_ref = F.avg_pool1d(xr, 2)
+        c = torch.randn_like(y_ref)
+        (y_ref * c).sum().backward()
+        xg = x.to(dev).requires_grad_(True)
+        y = ops.avg_pool2(xg)
+        assert torch.allclose(y.cpu(), y_ref, atol=1e-7)
+        (y * c.to(dev)).sum().backward()
+        assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-7)
+
+
+def test_residual_unit_fused_vs_oracle(dev, ops):
+    from rave_amd import cc
+    for (C, L, d, causal) in [(96, 300, 9, False), (24, 64, 3, True), (192, 40, 1, False)]:
+        g = torch.Generator().manual_seed(C + d)
+        x = torch.randn(2, C, L, generator=g)
+        w3 = torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C)
+        w1 = torch.randn(C, C, 1, generator=g) / math.sqrt(C)
+        pad = O.get_padding(3, dilation=d, mode="causal" if causal else "centered")
+        xr, w3r, w1r = (t.clone().requires_grad_(True) for t in (x, w3, w1))
+        h = O.cc_conv1d(F.leaky_relu(xr, 0.2), w3r, None, 1, d, pad)
+        y_ref = O.cc_conv1d(F.leaky_relu(h, 0.2), w1r, None, 1, 1, (0, 0)) + xr
+        cot = torch.randn(y_ref.shape, generator=g)
+        (y_ref * cot).sum().backward()
+        g3 = ops.ConvGeom(dilation=d, pad_left=pad[0], pad_right=pad[1], act=1, slope=0.2)
+        g1 = ops.ConvGeom(act=1, slope=0.2)
+        xg, w3g, w1g = (t.to(dev).requires_grad_(True) for t in (x, w3, w1))
+        y = ops.residual_unit(xg, w3g, w1g, g3, g1)
+        assert rel_l2(y, y_ref) < TOL_OP
+        (y * cot.to(dev)).sum().backward()
+        assert rel_l2(xg.grad, xr.grad) < TOL_OP
+        assert rel_l2(w3g.grad, w3r.grad) < TOL_OP
+        assert rel_l2(w1g.grad, w1r.grad) < TOL_OP
+
+
+def test_edge_cases(dev, ops):
+    geom = ops.ConvGeom(pad_left=1, pad_right=1)
+    w = torch.randn(8, 4, 3, device=dev)
+    y = ops.conv1d(torch.zeros(0, 4, 10, device=dev), w, None, geom=geom)
+    assert y.shape == (0, 8, 10)
+    with pytest.raises(RuntimeError):
+        ops.conv1d(torch.zeros(1, 4, 10), w.cpu(), None, geom=geom)      # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        ops.conv1d(torch.zeros(1, 5, 10, device=dev), w, None, geom=geom)  # channel mismatch
+
+
+# --------------------------------------------------------------------------- modules / golden
+def _build(golden, dev, causal=False):
+    from rave_amd import model as M
+    c = golden["config"]
+    m = M.build_v2(capacity=c["capacity"], latent_size=c["latent_size"], causal=causal)
+    missing, unexpected = m.load_state_dict(golden["state_dict"], strict=False)
+    assert not unexpected and set(missing) <= {"receptive_field"}, (missing, unexpected)
+    return m.to(dev).train()
+
+
+@pytest.mark.parametrize("name,causal", [("v2_tiny.pt", False), ("v2_tiny_causal.pt", True)])
+def test_modules_forward_golden(golden_dir, dev, name, causal):
+    g = _load(golden_dir, name)
+    m = _build(g, dev, causal)
+    x = g["x"].to(dev)
+    with torch.no_grad():
+        zp, x_mb = m.encode(x, return_mb=True)
+        assert rel_l2(x_mb, g["x_mb"]) < TOL_OP
+        assert rel_l2(zp, g["z_params"]) < TOL_E2E
+        z, reg = m.encoder.reparametrize(g["z_params"].to(dev), g["eps"].to(dev))
+        assert rel_l2(z, g["z"]) < 1e-6
+        y_mb = m.decoder(g["z"].to(dev))
+        assert rel_l2(y_mb, g["y_mb"]) < TOL_E2E
+        y_raw = m.decode(g["z"].to(dev))
+        assert rel_l2(y_raw, g["y_raw"]) < TOL_E2E
+        feats = m.discriminator(torch.cat([x, g["y_raw"].to(dev)], 0))
+        assert len(feats) == 8 and all(len(f) == 5 for f in feats)
+        for f, last, mid in zip(feats, g["feat_last"], g["feat_mid"]):
+            assert f[-1].shape == last.shape and f[2].shape == mid.shape
+            assert rel_l2(f[-1], last) < TOL_E2E
+            assert rel_l2(f[2], mid) < TOL_E2E
+
+
+@pytest.mark.parametrize("phase", ["vae", "dis", "gen"])
+def test_training_step_golden(golden_dir, dev, phase):
+    """The complete step (rave/model.py:288-413) on the HIP modules vs the reference's own step."""
+    g = _load(golden_dir, "v2_tiny.pt")
+    m = _build(g, dev)
+    m.warmed_up = phase != "vae"
+    m.configure_optimizers()
+    logged = m.training_step(g["x"].to(dev).clone(), 0 if phase != "gen" else 1, eps=g["eps"].to(dev))
+    ref = g[phase]
+    for k, v in ref["losses"].items():
+        if k in logged and torch.is_tensor(logged[k]):
+            assert abs(float(logged[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, gref in ref["grads"].items():
+        got = named[k].grad
+        assert got is not None, k
+        assert rel_l2(got, gref) < 5e-4, (k, rel_l2(got, gref))
+        checked += 1
+    assert checked >= 5
+
+
+def test_v2_full_size_forward_vs_oracle(dev):
+    """BASELINE config 2 geometry (v2, CAPACITY 96, 65536 samples), batch 2: PQMF -> EncoderV2 ->
+    reparametrize -> GeneratorV2 -> PQMF^-1 on the GPU vs the CPU oracle; <= 1e-4 relative L2."""
+    from rave_amd import model as M
+    cfg = O.v2_config()
+    sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+    m = M.build_v2()
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).train()
+    x = O.synthetic_batch(2, 1, 65536)
+    eps = torch.randn(2, 128, 32, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = O.rave_forward(x, sd, cfg, eps)
+        zp, x_mb = m.encode(x.to(dev), return_mb=True)
+        z, _ = m.encoder.reparametrize(zp, eps.to(dev))
+        y_mb = m.decoder(z)
+        y_raw = m.decode(z)
+    assert rel_l2(x_mb, ref["x_mb"]) < TOL_OP
+    assert rel_l2(zp, ref["z_params"]) < TOL_E2E
+    assert rel_l2(y_mb, ref["y_mb"]) < TOL_E2E
+    assert rel_l2(y_raw, ref["y_raw"]) < TOL_E2E

@@ -1,0 +1,204 @@
+"""CPU tests that PIN THE ORACLE (oracle/rave_oracle.py):
+  * against the committed golden fixtures produced by the unmodified reference
+    (oracle/make_golden.py) -- always;
+  * against the reference modules themselves when /root/reference is present (build container).
+"""
+import os
+
+import pytest
+import torch
+
+import rave_oracle as O
+from conftest import rel_l2
+
+TOL = 2e-6  # same ATen ops as the reference; only thread-count / summation-order noise is allowed
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def test_pqmf_design_matches_reference_buffers(golden_dir):
+    g = _load(golden_dir, "pqmf.pt")
+    b = O.pqmf_buffers(100, 16)
+    assert b["h"].shape == (377,)
+    assert rel_l2(b["h"], g["h"]) < 1e-6
+    assert rel_l2(b["hk"], g["hk"]) < 1e-6
+    assert rel_l2(b["forward_conv.weight"], g["w_fwd"]) < 1e-6
+    assert rel_l2(b["inverse_conv.weight"], g["w_inv"]) < 1e-6
+
+
+def test_pqmf_closed_form_hk():
+    """hk[k,t] = 2 h[t] cos((2k+1) pi/32 (t-188) + (-1)^k pi/4)."""
+    import math
+    b = O.pqmf_buffers(100, 16)
+    h = b["h"].double()
+    k = torch.arange(16, dtype=torch.float64).reshape(-1, 1)
+    t = torch.arange(377, dtype=torch.float64) - 188
+    hk = 2 * h * torch.cos((2 * k + 1) * math.pi / 32 * t + (-1) ** k * math.pi / 4)
+    assert (b["hk"][:, 67:67 + 377].double() - hk).abs().max() < 2e-7
+    assert b["hk"][:, :67].abs().max() == 0 and b["hk"][:, 67 + 377:].abs().max() == 0
+
+
+def test_pqmf_analysis_synthesis_golden(golden_dir):
+    g = _load(golden_dir, "pqmf.pt")
+    x = g["x"].reshape(-1, 1, g["x"].shape[-1])
+    y = O.pqmf_analysis(x, g["w_fwd"])
+    assert rel_l2(y, g["y"]) < TOL
+    assert rel_l2(O.pqmf_synthesis(g["y"], g["w_inv"]), g["x_rec"]) < TOL
+    assert rel_l2(O.pqmf_analysis(x, g["w_fwd"], causal=True), g["y_causal"]) < TOL
+    assert rel_l2(O.pqmf_synthesis(g["y_causal"], g["w_inv"], causal=True), g["x_rec_causal"]) < TOL
+
+
+def test_pqmf_direct_formula(golden_dir):
+    """SURVEY.md section 8a a5 closed forms, float64 numpy loops on a small slice."""
+    import numpy as np
+    g = _load(golden_dir, "pqmf.pt")
+    x = g["x"][0, 0].double().numpy()
+    wf = g["w_fwd"][:, 0].double().numpy()
+    xpad = np.concatenate([np.zeros(256), x, np.zeros(256)])
+    for n in (0, 1, 7, 128, 255):
+        for k in (0, 1, 6, 15):
+            v = float(np.dot(wf[k], xpad[16 * n:16 * n + 513]))
+            if k % 2 == 1 and n % 2 == 0:
+                v = -v
+            assert abs(v - float(g["y"][0, k, n])) < 1e-5
+    # synthesis: out[16n+i] = 16 sum_c sum_t Wi[15-i,c,t] u[c,n+t-16], u = s*y
+    wi = g["w_inv"].double().numpy()
+    y = g["y"][0].double().numpy().copy()
+    y[1::2, ::2] *= -1
+    upad = np.concatenate([np.zeros((16, 16)), y, np.zeros((16, 16))], axis=1)
+    for n in (0, 3, 100, 255):
+        for i in (0, 5, 15):
+            v = 16.0 * float(np.sum(wi[15 - i] * upad[:, n:n + 33]))
+            assert abs(v - float(g["x_rec"][0, 0, 16 * n + i])) < 1e-5
+
+
+def test_reverse_half_is_a_sign_involution():
+    x = torch.randn(2, 16, 10)
+    y = O.reverse_half(x)
+    assert torch.equal(O.reverse_half(y), x)
+    sign = (y / x)
+    for k in range(16):
+        for n in range(10):
+            assert sign[0, k, n] == (-1 if (k % 2 == 1 and n % 2 == 0) else 1)
+
+
+def test_pqmf_roundtrip_is_near_perfect_reconstruction():
+    """Appendix B #4: near-PR only (~1e-3), delay 16 samples for the cached form."""
+    b = O.pqmf_buffers(100, 16)
+    x = O.synthetic_batch(1, 1, 8192, seed=5)
+    y = O.pqmf_analysis(x, b["forward_conv.weight"])
+    xr = O.pqmf_synthesis(y, b["inverse_conv.weight"])
+    err = rel_l2(xr[..., 1024 + 16:-1024], x[..., 1024:-1024 - 16])
+    assert err < 5e-3
+
+
+@pytest.mark.parametrize("name,causal", [("v2_tiny.pt", False), ("v2_tiny_causal.pt", True)])
+def test_forward_products_golden(golden_dir, name, causal):
+    g = _load(golden_dir, name)
+    c = g["config"]
+    cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"], causal=causal)
+    sd = g["state_dict"]
+    with torch.no_grad():
+        out = O.rave_forward(g["x"], sd, cfg, g["eps"])
+        assert rel_l2(out["x_mb"], g["x_mb"]) < TOL
+        assert rel_l2(out["z_params"], g["z_params"]) < TOL
+        assert rel_l2(out["z"], g["z"]) < TOL
+        assert rel_l2(out["y_mb"], g["y_mb"]) < TOL
+        assert rel_l2(out["y_raw"], g["y_raw"]) < TOL
+        feats = O.combine_discriminators(torch.cat([g["x"], g["y_raw"]], 0), sd, cfg)
+        assert len(feats) == 8 and all(len(f) == 5 for f in feats)
+        for f, last, mid in zip(feats, g["feat_last"], g["feat_mid"]):
+            assert rel_l2(f[-1], last) < 5e-6
+            assert rel_l2(f[2], mid) < 5e-6
+
+
+@pytest.mark.parametrize("phase", ["vae", "dis", "gen"])
+def test_training_step_losses_and_grads_golden(golden_dir, phase):
+    g = _load(golden_dir, "v2_tiny.pt")
+    c = g["config"]
+    cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.startswith("pqmf.h")) for k, v in g["state_dict"].items()}
+    x = g["x"].clone().requires_grad_(True)
+    loss_gen, loss_dis, parts, _ = O.generator_losses(x, sd, cfg, g["eps"], warmed_up=phase != "vae")
+    ref = g[phase]
+    for k, v in ref["losses"].items():
+        if k == "loss_dis":
+            if phase != "vae":
+                assert abs(float(loss_dis) - float(v)) < 1e-4 * max(1.0, abs(float(v)))
+            continue
+        if k not in parts:   # pred_real / pred_fake / beta_factor: logging only
+            continue
+        assert abs(float(parts[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), k
+    (loss_dis if phase == "dis" else loss_gen).backward()
+    checked = 0
+    for k, gref in ref["grads"].items():
+        got = sd[k].grad
+        if got is None:
+            assert float(gref.abs().max()) == 0.0
+            continue
+        assert rel_l2(got, gref) < 2e-4, (k, rel_l2(got, gref))
+        checked += 1
+    assert checked >= 5
+
+
+def test_init_state_dict_layout_matches_golden(golden_dir):
+    g = _load(golden_dir, "v2_tiny.pt")
+    c = g["config"]
+    cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"])
+    mine = O.init_state_dict(cfg)
+    ref = {k: v for k, v in g["state_dict"].items() if k != "encoder.warmed_up"}
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+
+
+# ---- direct comparison with the unmodified reference (build container only) -----------------
+def _have_reference():
+    import ref_import
+    return ref_import.reference_available()
+
+
+@pytest.mark.skipif(not _have_reference(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("causal", [False, True])
+def test_oracle_equals_reference_modules(causal):
+    from ref_models import build_reference_rave
+    torch.manual_seed(3)
+    m = build_reference_rave("v2", capacity=10, latent_size=12, causal=causal)
+    m.train()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cfg = O.v2_config(capacity=10, latent_size=12, causal=causal)
+    x = O.synthetic_batch(2, 1, 8192, seed=9)
+    with torch.no_grad():
+        zp, xmb = m.encode(x, return_mb=True)
+        out_mb = O.pqmf_encode(x, sd["pqmf.forward_conv.weight"], causal)
+        assert rel_l2(out_mb, xmb) < TOL
+        assert rel_l2(O.encoder_v2(out_mb, sd, cfg), zp) < TOL
+        eps = torch.randn(2, 12, zp.shape[-1])
+        z, _ = O.reparametrize(zp, eps)
+        assert rel_l2(O.generator_v2(z, sd, cfg), m.decoder(z)) < TOL
+        yr = m.decode(z)
+        assert rel_l2(O.pqmf_decode(m.decoder(z), sd["pqmf.inverse_conv.weight"], 1, causal), yr) < TOL
+        fr = m.discriminator(torch.cat([x, yr], 0))
+        fo = O.combine_discriminators(torch.cat([x, yr], 0), sd, cfg)
+        for a, b in zip(fr, fo):
+            for u, v in zip(a, b):
+                assert rel_l2(v, u) < 5e-6
+        d_ref = m.audio_distance(x, yr)["spectral_distance"]
+        assert abs(float(O.audio_distance_v1(x, yr, cfg)) - float(d_ref)) < 1e-4
+    build_reference_rave("v2", capacity=4, latent_size=4, causal=False)  # reset the causal binding
+
+
+@pytest.mark.skipif(not _have_reference(), reason="/root/reference not present (GPU box)")
+def test_reference_polyphase_and_classic_forms_agree_with_cached():
+    """CachedPQMF.forward == polyphase_forward == classic_forward."""
+    from ref_import import import_reference
+    rave = import_reference()
+    from rave import pqmf as rp
+    b = O.pqmf_buffers(100, 16)
+    x = O.synthetic_batch(2, 1, 4096, seed=1)
+    y = O.pqmf_analysis(x, b["forward_conv.weight"])
+    yp = rp.reverse_half(rp.polyphase_forward(x, b["hk"]))
+    yc = rp.reverse_half(rp.classic_forward(x, b["hk"]))
+    assert rel_l2(yp, y) < 2e-6 and rel_l2(yc, y) < 2e-6
