@@ -47,26 +47,39 @@ def cpu_baseline(n_signal: int, budget_s: float = 20.0):
     b = 2
     x = O.synthetic_batch(b, 1, n_signal)
     eps = torch.randn(b, cfg.latent_size, n_signal // 2048)
-    times = []
-    t_start = time.perf_counter()
-    for i in range(6):
+
+    def one():
         t0 = time.perf_counter()
         opt.zero_grad()
         xx = x.clone().requires_grad_(True)
         loss, _, _, _ = O.generator_losses(xx, full, cfg, eps, warmed_up=False)
         loss.backward()
         opt.step()
-        dt = time.perf_counter() - t0
-        if i > 0:
-            times.append(dt)
-        if time.perf_counter() - t_start > budget_s and len(times) >= 2:
+        return time.perf_counter() - t0
+
+    # a 2-clip step cannot feed every core of a big host: pick the best thread count first
+    nproc = os.cpu_count() or 1
+    best_t, best_n = None, None
+    t_start = time.perf_counter()
+    for n in sorted({nproc, min(nproc, 64), min(nproc, 32), min(nproc, 16)}, reverse=True):
+        torch.set_num_threads(n)
+        one()
+        dt = one()
+        if best_t is None or dt < best_t:
+            best_t, best_n = dt, n
+        if time.perf_counter() - t_start > budget_s:
             break
+    torch.set_num_threads(best_n)
+    times = [best_t]
+    while len(times) < 4 and time.perf_counter() - t_start < 1.5 * budget_s:
+        times.append(one())
     times.sort()
     med = times[len(times) // 2]
-    return {"value": b * n_signal / med, "unit": "samples/s", "cores": torch.get_num_threads(),
+    return {"value": b * n_signal / med, "unit": "samples/s", "cores": best_n, "host_cores": nproc,
             "kind": "port",
             "sample": f"v2 VAE-phase training step (fwd+losses+bwd+Adam), batch {b} x {n_signal} samples, "
-                      f"median of {len(times)} steps after 1 warm-up, torch CPU fp32 oracle"}
+                      f"median of {len(times)} steps at the best of several torch thread counts ({best_n}), "
+                      f"torch CPU fp32 oracle (oracle/rave_oracle.py)"}
 
 
 def main():

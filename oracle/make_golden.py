@@ -78,6 +78,27 @@ def grads_of(model):
     return {k: t(named[k].grad) for k in SELECT if named[k].grad is not None}
 
 
+def oracle_cotangents(sd, x, eps, cfg, phase, ref_grads):
+    """dL/dy_raw, dL/dy_mb, dL/dz_params of the step, evaluated by the oracle IN THIS CONTAINER.
+    The spectral-loss backward is ill-conditioned (d log(|STFT|+1e-7) reaches 1e7), so these
+    cotangents are only reproducible to ~1 % across machines; storing them lets the parity
+    tests inject exactly the values the golden parameter gradients were produced with.  The
+    oracle's parameter gradients are asserted equal to the reference's first."""
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point() and not k.startswith("pqmf.h"))
+              for k, v in sd.items()}
+    xx = x.clone().requires_grad_(True)
+    loss_gen, loss_dis, _, out = O.generator_losses(xx, leaves, cfg, eps, warmed_up=phase != "vae")
+    for k in ("y_raw", "y_mb", "z_params"):
+        if out[k].requires_grad:
+            out[k].retain_grad()
+    (loss_dis if phase == "dis" else loss_gen).backward()
+    for k, gref in ref_grads.items():
+        got = leaves[k].grad
+        err = float((got - gref).norm() / gref.norm())
+        assert err < 1e-5, (phase, k, err)
+    return {k: t(out[k].grad) for k in ("y_raw", "y_mb", "z_params") if out[k].grad is not None}
+
+
 def golden_v2_tiny(causal=False, name="v2_tiny.pt"):
     cap, lat, n_signal, batch = 6, 8, 32768, 2
     torch.manual_seed(0)
@@ -106,6 +127,8 @@ def golden_v2_tiny(causal=False, name="v2_tiny.pt"):
     torch.manual_seed(1234)
     m.training_step(x.clone(), 0)
     out["vae"] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)}, grads=grads_of(m))
+    ocfg = O.v2_config(capacity=cap, latent_size=lat, causal=causal)
+    out["vae"]["cotangents"] = oracle_cotangents(sd, x, eps, ocfg, "vae", out["vae"]["grads"])
     # GAN phase from the SAME initial weights
     m.load_state_dict({**m.state_dict(), **sd})
     attach_optimizers(m)
@@ -121,6 +144,7 @@ def golden_v2_tiny(causal=False, name="v2_tiny.pt"):
     torch.manual_seed(1234)
     m.training_step(x.clone(), 1)   # generator step
     out["gen"] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)}, grads=grads_of(m))
+    out["gen"]["cotangents"] = oracle_cotangents(sd, x, eps, ocfg, "gen", out["gen"]["grads"])
     torch.save(out, os.path.join(OUT, name))
     nbytes = os.path.getsize(os.path.join(OUT, name))
     print(name, nbytes, "bytes;", {k: float(v) for k, v in out["vae"]["losses"].items()})

@@ -241,6 +241,7 @@ extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const 
                                  float* y, rh_stream_t stream) {
     ConvP p{};
     if (int e = rh_conv_fill_fwd(d, &p)) return e;
+    if (d->batch == 0 || d->l_out == 0) return RH_OK;
     RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv1d_fwd: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
     p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
@@ -253,6 +254,7 @@ extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, 
                                       float* dx, rh_stream_t stream) {
     ConvP p{};
     if (int e = rh_conv_fill_dgrad(d, &p)) return e;
+    if (d->batch == 0 || d->l_in == 0) return RH_OK;
     RH_REQUIRE(dy && wp_bwd && dx, RH_ERR_INVALID, "conv1d_bwd_data: null pointer");
     RH_REQUIRE(d->act == RH_ACT_NONE || x, RH_ERR_INVALID, "conv1d_bwd_data: act needs the forward input");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_data: snake needs alpha");
@@ -271,7 +273,7 @@ extern "C" int rh_conv1d_bwd_weight_f32(const rh_conv1d_desc* d, const float* dy
                                         const float* snake_alpha, float* dw, float* dbias,
                                         void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
     if (int e = validate(d)) return e;
-    RH_REQUIRE(dy && x && dw, RH_ERR_INVALID, "conv1d_bwd_weight: null pointer");
+    RH_REQUIRE(dw && (d->batch == 0 || (dy && x)), RH_ERR_INVALID, "conv1d_bwd_weight: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_weight: snake needs alpha");
     return rh_wgrad_run(d, dy, x, snake_alpha, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
 }

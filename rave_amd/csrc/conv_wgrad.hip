@@ -245,13 +245,14 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     if (!d->transposed) { p.R = dy; p.S = x; p.r_alpha = nullptr; p.s_alpha = alpha; }
     else                { p.R = x; p.S = dy; p.r_alpha = alpha; p.s_alpha = nullptr; }
     const long nw = (long)p.M * p.C * p.T;
-    if (dbias) {
+    if (dbias && d->batch > 0) {
         const int row = d->l_out * d->inner;
         hipLaunchKernelGGL(bias_grad_kernel, dim3(d->c_out), dim3(256), 0, stream, dy, dbias, d->batch, d->c_out, row);
         if (int e = rh_check_launch("conv1d_bias_grad")) return e;
     }
     if (p.B <= 0 || p.r_row <= 0) {
         (void)hipMemsetAsync(dw, 0, nw * sizeof(float), stream);
+        if (dbias) (void)hipMemsetAsync(dbias, 0, d->c_out * sizeof(float), stream);
         return RH_OK;
     }
     const WPlan w = plan(p);

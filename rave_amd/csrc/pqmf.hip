@@ -195,8 +195,8 @@ int launch(const PqmfP& p, bool w2b, hipStream_t stream) {
 }
 
 int check_common(const void* a, const void* b, const void* c, int rows, int n_band) {
-    RH_REQUIRE(a && b && c, RH_ERR_INVALID, "pqmf: null pointer");
     RH_REQUIRE(rows >= 0, RH_ERR_INVALID, "pqmf: rows < 0");
+    RH_REQUIRE(rows == 0 || (a && b && c), RH_ERR_INVALID, "pqmf: null pointer");
     RH_REQUIRE(n_band == kBands, RH_ERR_UNSUPPORTED, "pqmf: only n_band == 16 is implemented (got %d)", n_band);
     return RH_OK;
 }

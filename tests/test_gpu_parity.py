@@ -352,9 +352,33 @@ def test_modules_forward_golden(golden_dir, dev, name, causal):
             assert rel_l2(f[2], mid) < TOL_E2E
 
 
+def _oracle_step(g, phase, dtype=torch.float32):
+    """CPU oracle evaluation of the step of the golden fixture; returns (param grads, cotangents at
+    the hot-path outputs y_raw / y_mb / z_params, loss parts)."""
+    c = g["config"]
+    cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"])
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(
+        v.is_floating_point() and not k.startswith("pqmf.h")) for k, v in g["state_dict"].items()}
+    x = g["x"].to(dtype).clone().requires_grad_(True)
+    loss_gen, loss_dis, parts, out = O.generator_losses(x, sd, cfg, g["eps"].to(dtype), warmed_up=phase != "vae")
+    for k in ("y_raw", "y_mb", "z_params"):
+        if out[k].requires_grad:
+            out[k].retain_grad()
+    (loss_dis if phase == "dis" else loss_gen).backward()
+    cots = {k: out[k].grad for k in ("y_raw", "y_mb", "z_params")}
+    return sd, cots, parts
+
+
 @pytest.mark.parametrize("phase", ["vae", "dis", "gen"])
 def test_training_step_golden(golden_dir, dev, phase):
-    """The complete step (rave/model.py:288-413) on the HIP modules vs the reference's own step."""
+    """The complete step (rave/model.py:288-413) on the HIP modules vs the reference's own step.
+
+    Loss values must agree to 1e-4.  Gradients THROUGH the spectral losses are ill-conditioned in
+    fp32 for any implementation: d log(|STFT|+1e-7) reaches 1e7 on near-silent bins, so the
+    reference's own fp32 gradients differ from a float64 evaluation of the same step by 0.4-0.9 %
+    (measured, see DESIGN.md "parity").  They are therefore compared with the float64 oracle
+    gradient, allowing the same error class as the golden (reference fp32) gradient shows; the
+    tight check of the hot-path backward is test_hot_path_backward_with_reference_cotangents."""
     g = _load(golden_dir, "v2_tiny.pt")
     m = _build(g, dev)
     m.warmed_up = phase != "vae"
@@ -364,14 +388,49 @@ def test_training_step_golden(golden_dir, dev, phase):
     for k, v in ref["losses"].items():
         if k in logged and torch.is_tensor(logged[k]):
             assert abs(float(logged[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+    sd64, _, _ = _oracle_step(g, phase, torch.float64)
     named = dict(m.named_parameters())
     checked = 0
     for k, gref in ref["grads"].items():
         got = named[k].grad
         assert got is not None, k
-        assert rel_l2(got, gref) < 5e-4, (k, rel_l2(got, gref))
+        exact = sd64[k].grad
+        ref_err = rel_l2(gref, exact)          # the reference's own fp32 error on this gradient
+        err = rel_l2(got, exact)
+        assert err < max(5.0 * ref_err, 5e-4), (k, err, ref_err)
         checked += 1
     assert checked >= 5
+
+
+@pytest.mark.parametrize("phase", ["vae", "gen"])
+def test_hot_path_backward_with_reference_cotangents(golden_dir, dev, phase):
+    """Tight end-to-end check of the HIP backward.  The golden file stores dL/dy_raw and dL/dy_mb
+    exactly as they occurred in the reference's own step (the spectral-loss backward is only
+    reproducible to ~1 % across machines, so recomputing it here would blur the comparison);
+    injecting them at the hot-path outputs on the GPU must reproduce the reference's golden
+    parameter gradients to <= 2e-4 relative L2 (PQMF^-1 bwd, GeneratorV2 bwd, KL, EncoderV2 bwd)."""
+    g = _load(golden_dir, "v2_tiny.pt")
+    cots = g[phase]["cotangents"]
+    m = _build(g, dev)
+    x = g["x"].to(dev)
+    zp, x_mb = m.encode(x, return_mb=True)
+    if phase == "gen":   # warmed-up encoder output is detached (rave/blocks.py:742-744)
+        zp = zp.detach().requires_grad_(True)
+    z, reg = m.encoder.reparametrize(zp, g["eps"].to(dev))
+    y_mb = m.decoder(z)
+    y_raw = m.decode(z)
+    torch.autograd.backward([y_raw, y_mb, reg],
+                            [cots["y_raw"].to(dev), cots["y_mb"].to(dev), torch.ones((), device=dev)])
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, gref in g[phase]["grads"].items():
+        if k.startswith("discriminator."):
+            continue
+        got = named[k].grad
+        assert got is not None, k
+        assert rel_l2(got, gref) < 2e-4, (k, rel_l2(got, gref))
+        checked += 1
+    assert checked >= (5 if phase == "vae" else 3)
 
 
 def test_v2_full_size_forward_vs_oracle(dev):

