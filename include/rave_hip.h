@@ -108,13 +108,20 @@ int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd, f
  * EncoderV2 / GeneratorV2 / discriminator.ConvNet. */
 int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_fwd,
                       const float* bias, const float* snake_alpha, const float* residual,
-                      float* y, rh_stream_t stream);
+                      float* y, void* workspace, int64_t workspace_bytes, rh_stream_t stream);
+/* Optional scratch for rh_conv1d_fwd_f32 / rh_conv1d_bwd_data_f32 (0 = none needed).  Geometries
+ * whose output is too small to fill 256 CUs (short sequences x many channels) split the
+ * reduction over (tap, input-channel) chunks across workgroups; the partial sums live in this
+ * scratch and are combined in a fixed order (deterministic).  Passing NULL / too few bytes is
+ * legal: the launch then runs unsplit (slower, same accumulation class). */
+int64_t rh_conv1d_fwd_workspace_bytes(const rh_conv1d_desc* d);
+int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d);
 
 /* dx = act'(x) * conv_bwd_data(dy) + add.   `x` is the forward input (needed when act != NONE),
  * `add` (B,c_in,l_in*inner) may be NULL (residual-branch gradient). */
 int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd,
                            const float* x, const float* snake_alpha, const float* add, float* dx,
-                           rh_stream_t stream);
+                           void* workspace, int64_t workspace_bytes, rh_stream_t stream);
 
 /* Bytes of scratch rh_conv1d_bwd_weight_f32 needs for this geometry. */
 int64_t rh_conv1d_workspace_bytes(const rh_conv1d_desc* d);

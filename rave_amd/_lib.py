@@ -42,8 +42,10 @@ def _load() -> C.CDLL:
         "rh_weight_norm_bwd_f32": ([P, P, P, P, I64, I64, P, P, P], C.c_int),
         "rh_conv1d_packed_floats": ([D, C.c_int], I64),
         "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
-        "rh_conv1d_fwd_f32": ([D, P, P, P, P, P, P, P], C.c_int),
-        "rh_conv1d_bwd_data_f32": ([D, P, P, P, P, P, P, P], C.c_int),
+        "rh_conv1d_fwd_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
+        "rh_conv1d_bwd_data_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
+        "rh_conv1d_fwd_workspace_bytes": ([D], I64),
+        "rh_conv1d_bwd_data_workspace_bytes": ([D], I64),
         "rh_conv1d_workspace_bytes": ([D], I64),
         "rh_conv1d_bwd_weight_f32": ([D, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_pqmf_analysis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),

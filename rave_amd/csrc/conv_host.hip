@@ -236,9 +236,22 @@ extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float
     return RH_OK;
 }
 
+extern "C" int64_t rh_conv1d_fwd_workspace_bytes(const rh_conv1d_desc* d) {
+    ConvP p{};
+    if (rh_conv_fill_fwd(d, &p)) return -1;
+    return rh_conv_splitk_workspace(p);
+}
+
+extern "C" int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d) {
+    ConvP p{};
+    if (rh_conv_fill_dgrad(d, &p)) return -1;
+    p.epi_act = d->act;
+    return rh_conv_splitk_workspace(p);
+}
+
 extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_fwd,
                                  const float* bias, const float* snake_alpha, const float* residual,
-                                 float* y, rh_stream_t stream) {
+                                 float* y, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
     ConvP p{};
     if (int e = rh_conv_fill_fwd(d, &p)) return e;
     if (d->batch == 0 || d->l_out == 0) return RH_OK;
@@ -246,12 +259,14 @@ extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const 
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
     p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
     p.in_alpha = snake_alpha; p.mul_alpha = nullptr;
-    return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_fwd" : "conv1d_fwd");
+    return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_fwd" : "conv1d_fwd", workspace,
+                          workspace_bytes);
 }
 
 extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd,
                                       const float* x, const float* snake_alpha, const float* add,
-                                      float* dx, rh_stream_t stream) {
+                                      float* dx, void* workspace, int64_t workspace_bytes,
+                                      rh_stream_t stream) {
     ConvP p{};
     if (int e = rh_conv_fill_dgrad(d, &p)) return e;
     if (d->batch == 0 || d->l_in == 0) return RH_OK;
@@ -261,7 +276,8 @@ extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, 
     p.in = dy; p.wp = wp_bwd; p.out = dx; p.bias = nullptr; p.add = add;
     p.mul_src = d->act == RH_ACT_NONE ? nullptr : x;
     p.in_alpha = nullptr; p.mul_alpha = snake_alpha;
-    return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_bwd_data" : "conv1d_bwd_data");
+    return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_bwd_data" : "conv1d_bwd_data",
+                          workspace, workspace_bytes);
 }
 
 extern "C" int64_t rh_conv1d_workspace_bytes(const rh_conv1d_desc* d) {

@@ -211,7 +211,13 @@ int launch_cfg(ConvP& p, hipStream_t stream, const char* what) {
 
 }  // namespace
 
-int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what) {
+int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes) {
+    if (p.B <= 0 || p.ncols <= 0 || p.M <= 0) return RH_OK;
+    if (rh_conv_dma_eligible(p)) return rh_conv_launch_dma(p, stream, what, ws, ws_bytes);
+    return rh_conv_launch_sync(p, stream, what);
+}
+
+int rh_conv_launch_sync(ConvP& p, hipStream_t stream, const char* what) {
     if (p.B <= 0 || p.ncols <= 0 || p.M <= 0) return RH_OK;
     if (p.M <= 32) return launch_cfg<1, 2, 1, 4>(p, stream, what);
     if (p.M <= 64) return launch_cfg<2, 1, 1, 4>(p, stream, what);

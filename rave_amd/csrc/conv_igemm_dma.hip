@@ -1,0 +1,366 @@
+// Implicit-GEMM convolution, software-pipelined with asynchronous global->LDS DMA
+// (buffer_load ... lds, gfx950): while the matrix cores work on K-chunk i out of LDS stage i&1,
+// the DMA engine fills stage (i+1)&1 with the next weight and input tiles -- no staging registers,
+// one workgroup barrier per chunk.  Zero padding (left/right/causal pads, MPD fold pad, ragged
+// channel/batch tails) comes from the buffer descriptor's bounds check: invalid lanes are given
+// an out-of-range offset and the hardware writes 0.0 into LDS.
+//
+// Because DMA cannot transform data in flight, the fused pre-activation (LeakyReLU) is applied
+// when the B operand is read from LDS (2 VALU per 64-cycle MFMA group -- free); Snake keeps the
+// register-staged kernel of conv_igemm.hip.  Same math, same accumulation order per output as the
+// synchronous kernel: exact f32, k-ordered fmaf chains.
+#include <mutex>
+#include "conv_params.hpp"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ int ibase_of(int n, int inner, int is) {
+    if (inner == 1) return n * is;
+    const int r = n / inner;
+    return r * is * inner + (n - r * inner);
+}
+__device__ __forceinline__ int oidx_of(int n, int inner, int os, int oph) {
+    if (inner == 1) return n * os + oph;
+    const int r = n / inner;
+    return (r * os + oph) * inner + (n - r * inner);
+}
+__device__ __forceinline__ unsigned mdiv(unsigned n, unsigned magic) { return (n * magic) >> 20; }
+
+constexpr unsigned kOOB = 0x80000000u;  // >= any descriptor size we accept -> DMA writes zeros
+
+template <int TM, int TN, int WM, int WN, bool LEAKY>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP p) {
+    constexpr int BM = TM * WM * 32;
+    constexpr int NW = WM * WN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    const int zsl = blockIdx.z / p.nphase;          // K slice
+    const int phase = blockIdx.z - zsl * p.nphase;
+    const int ntaps = p.ph_ntaps[phase];
+    const int tap0 = p.ph_tap0[phase];
+    const int minoff = p.ph_minoff[phase];
+    const int oph = p.ph_oph[phase];
+    const unsigned wofs = (unsigned)p.ph_wofs[phase];
+
+    const int bt = blockIdx.x / p.tiles_per_b;
+    const int nt = blockIdx.x - bt * p.tiles_per_b;
+    const int b0 = bt * p.nb;
+    const int n0 = nt * p.bnl;
+    const int m0 = blockIdx.y * BM;
+    const int inner = p.inner, is = p.is;
+    const int pitch = p.segs * 64;
+    const int ib0 = ibase_of(n0, inner, is);
+    const int lo = ib0 + minoff * inner;
+
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.w_bytes, 0x00020000);
+
+    int xb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = (wn * TN + tn) * 32 + j;
+        const int bl = col >> p.bnl_shift;
+        const int nl = col & (p.bnl - 1);
+        const int n = min(n0 + nl, p.ncols - 1);
+        xb[tn] = (bl * p.ck + kh) * pitch + ibase_of(n, inner, is) - ib0;
+    }
+    const int arow = wm * TM * 32 + j + kh * BM;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int wrows = ntaps * p.ck;
+    const int w_instrs = (wrows * BM + 255) >> 8;   // 256 floats (64 lanes x 16 B) per DMA instruction
+    const int xrows = p.nb * p.ck;
+    const int x_instrs = xrows * p.segs;            // 64 floats (64 lanes x 4 B) per DMA instruction
+
+    auto issue = [&](int c0, float* stage) {
+        // weights: LDS image [tap][c][BM], flat
+        for (int q = wave; q < w_instrs; q += NW) {
+            const unsigned f = (unsigned)q * 256u + (unsigned)lane * 4u;
+            const unsigned kr = f / (unsigned)BM;
+            const unsigned col = f - kr * BM;
+            const unsigned t = mdiv(kr, p.magic_ck);
+            const unsigned c = kr - t * p.ck;
+            const unsigned ch = c0 + c, m = m0 + col;
+            unsigned off = kOOB;
+            if (kr < (unsigned)wrows && ch < (unsigned)p.C && m < (unsigned)p.Mp)
+                off = (wofs + (t * p.C + ch) * p.Mp + m) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(stage + q * 256), 16, off, 0, 0, 0);
+        }
+        // input tile: rows (batch item, channel), 64-float segments
+        float* xs = stage + p.wlds_floats;
+        for (int row = wave; row < xrows; row += NW) {
+            const unsigned bl = mdiv((unsigned)row, p.magic_ck);
+            const unsigned c = row - bl * p.ck;
+            const unsigned b = b0 + bl, ch = c0 + c;
+            const bool rv = b < (unsigned)p.B && ch < (unsigned)p.C;
+            const unsigned rbase = (b * p.C + ch) * (unsigned)p.in_row;
+            float* dst = xs + row * pitch;
+            for (int seg = 0; seg < p.segs; ++seg) {
+                const int fpos = lo + seg * 64 + lane;
+                unsigned off = kOOB;
+                if (rv && fpos >= 0 && fpos < p.in_valid) off = (rbase + (unsigned)fpos) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)(dst + seg * 64), 4, off, 0, 0, 0);
+            }
+        }
+    };
+
+    const int total_chunks = (p.C + p.ck - 1) / p.ck;
+    const int chunk0 = zsl * p.chunks_per_split;
+    const int nchunks = min(p.chunks_per_split, total_chunks - chunk0);
+    issue(chunk0 * p.ck, smem);
+    for (int i = 0; i < nchunks; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // chunk i landed for every wave; everyone is done with the other stage
+        if (i + 1 < nchunks) issue((chunk0 + i + 1) * p.ck, smem + ((i + 1) & 1) * p.stage_floats);
+        const float* w_lds = smem + (i & 1) * p.stage_floats;
+        const float* x_lds = w_lds + p.wlds_floats;
+        for (int t = 0; t < ntaps; ++t) {
+            const int toff = (p.off[tap0 + t] - minoff) * inner;
+            const float* wl = w_lds + t * p.ck * BM + arow;
+            const float* xl = x_lds + toff;
+            // 4 k-steps (8 channels) per trip: the LDS reads of later steps overlap earlier MFMAs
+            int c = 0;
+            for (; c + 8 <= p.ck; c += 8) {
+                float a[4][TM], b[4][TN];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) a[u][tm] = wl[(c + 2 * u) * BM + tm * 32];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = xl[xb[tn] + (c + 2 * u) * pitch];
+                        if (LEAKY) v = v > 0.f ? v : v * p.in_slope;
+                        b[u][tn] = v;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][tm], b[u][tn], acc[tm][tn], 0, 0, 0);
+            }
+            for (; c < p.ck; c += 2) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm] = wl[c * BM + tm * 32];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    float v = xl[xb[tn] + c * pitch];
+                    if (LEAKY) v = v > 0.f ? v : v * p.in_slope;
+                    b[tn] = v;
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, activation derivative, residual / gradient add ----
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = (wn * TN + tn) * 32 + j;
+        const int bl = col >> p.bnl_shift;
+        const int nl = col & (p.bnl - 1);
+        const int n = n0 + nl, b = b0 + bl;
+        if (n >= p.ncols || b >= p.B) continue;
+        const int oi = oidx_of(n, inner, p.os, oph);
+        if (oi >= p.out_valid) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < p.M) {
+                    const long idx = ((long)b * p.M + m) * p.out_row + oi;
+                    float v = acc[tm][tn][r];
+                    if (p.ksplit > 1) {
+                        p.part[(long)zsl * p.part_stride + idx] = v;
+                        continue;
+                    }
+                    if (p.bias) v += p.bias[m];
+                    if (p.mul_src) {
+                        const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
+                        v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
+                    }
+                    if (p.add) v += p.add[idx];
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+unsigned magic_of(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
+
+// out = epi( sum_z part[z] ) for split-K launches (ordered sum -> deterministic)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvP p, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long row = e / p.out_valid;
+    const int oi = (int)(e - row * p.out_valid);
+    const int m = (int)(row % p.M);
+    const long idx = row * p.out_row + oi;
+    float v = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) v += p.part[(long)z * p.part_stride + idx];
+    if (p.bias) v += p.bias[m];
+    if (p.mul_src) {
+        const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
+        v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
+    }
+    if (p.add) v += p.add[idx];
+    p.out[idx] = v;
+}
+
+struct Plan { int blocks, total_chunks, ksplit, chunks_per_split; };
+
+Plan plan_split(const ConvP& p, int BM, int col_tiles) {
+    Plan pl{};
+    pl.blocks = col_tiles * rh_cdiv(p.M, BM) * p.nphase;
+    pl.total_chunks = rh_cdiv(p.C, p.ck);
+    int z = 1;
+    if (pl.blocks < 512) {
+        z = rh_cdiv(768, pl.blocks);
+        const int zmax = pl.total_chunks / 2;
+        if (z > zmax) z = zmax;
+        if (z > 16) z = 16;
+        if (z < 1) z = 1;
+    }
+    pl.chunks_per_split = rh_cdiv(pl.total_chunks, z);
+    pl.ksplit = rh_cdiv(pl.total_chunks, pl.chunks_per_split);
+    return pl;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool plan_only = false,
+               int64_t* want = nullptr) {
+    constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
+    int bnl = BN;
+    if (p.ncols < BN) {
+        bnl = 32;
+        while (bnl < p.ncols) bnl <<= 1;
+    }
+    p.bnl = bnl;
+    p.bnl_shift = __builtin_ctz(bnl);
+    p.nb = BN / bnl;
+    p.tiles_per_b = rh_cdiv(p.ncols, bnl);
+    int span = 0, maxtaps = 1;
+    for (int i = 0; i < p.nphase; ++i) {
+        span = span > p.ph_maxoff[i] - p.ph_minoff[i] ? span : p.ph_maxoff[i] - p.ph_minoff[i];
+        maxtaps = maxtaps > p.ph_ntaps[i] ? maxtaps : p.ph_ntaps[i];
+    }
+    int width;
+    if (p.inner == 1)
+        width = (bnl - 1) * p.is + span + 1;
+    else
+        width = ((bnl - 1) / p.inner + 1) * p.is * p.inner + p.inner + span * p.inner + 1;
+    p.segs = rh_cdiv(width, 64);
+    p.pitch = p.segs * 64;
+    const int budget = 10 * 1024;  // floats per stage: 2 stages x 40 KiB -> two workgroups per CU
+    const int per_ch = maxtaps * BM + p.nb * p.pitch;
+    int ck = (budget - 256) / per_ch;
+    ck &= ~1;
+    if (ck > 32) ck = 32;
+    if (ck < 2) ck = 2;
+    const int cmax = (p.C + 1) & ~1;
+    if (ck > cmax) ck = cmax;
+    p.ck = ck;
+    p.wlds_floats = (maxtaps * ck * BM + 255) & ~255;
+    p.stage_floats = p.wlds_floats + p.nb * ck * p.pitch;
+    p.magic_segs = magic_of(p.segs);
+    p.magic_ck = magic_of(ck);
+    const size_t lds = sizeof(float) * 2 * (size_t)p.stage_floats;
+    const int col_tiles = rh_cdiv(p.B, p.nb) * p.tiles_per_b;
+    Plan pl = plan_split(p, BM, col_tiles);
+    p.part_stride = (long)p.B * p.M * p.out_row;
+    const int64_t need = pl.ksplit > 1 ? (int64_t)pl.ksplit * p.part_stride * (int64_t)sizeof(float) : 0;
+    if (plan_only) {
+        *want = lds > 160 * 1024 ? 0 : need;
+        return RH_OK;
+    }
+    if (lds > 160 * 1024) return rh_conv_launch_sync(p, stream, what);
+    if (need > 0 && (!ws || ws_bytes < need)) {   // no scratch offered: run unsplit (slower, same result class)
+        pl.ksplit = 1;
+        pl.chunks_per_split = pl.total_chunks;
+    }
+    p.ksplit = pl.ksplit;
+    p.chunks_per_split = pl.chunks_per_split;
+    p.part = (float*)ws;
+    auto launch = [&](auto kern) {
+        dim3 grid(col_tiles, rh_cdiv(p.M, BM), p.nphase * p.ksplit);
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+    };
+    if (p.in_act == RH_ACT_LEAKY) {
+        auto kern = conv_igemm_dma_kernel<TM, TN, WM, WN, true>;
+        static std::once_flag once;
+        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        launch(kern);
+    } else {
+        auto kern = conv_igemm_dma_kernel<TM, TN, WM, WN, false>;
+        static std::once_flag once;
+        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        launch(kern);
+    }
+    if (int e = rh_check_launch(what)) return e;
+    if (p.ksplit > 1) {
+        const long total = (long)p.B * p.M * p.out_valid;
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, p, total);
+        return rh_check_launch("conv_splitk_finalize");
+    }
+    return RH_OK;
+}
+
+void fill_sizes(ConvP& p) {
+    unsigned long long wtaps = 0;
+    for (int i = 0; i < p.nphase; ++i) wtaps += p.ph_ntaps[i];
+    p.in_bytes = (unsigned)(4ull * p.B * p.C * (unsigned long long)p.in_row);
+    p.w_bytes = (unsigned)(4ull * wtaps * p.C * p.Mp);
+}
+
+}  // namespace
+
+bool rh_conv_dma_eligible(const ConvP& p) {
+    if (p.in_act == RH_ACT_SNAKE) return false;
+    const unsigned long long in_b = 4ull * p.B * p.C * (unsigned long long)p.in_row;
+    unsigned long long wtaps = 0;
+    for (int i = 0; i < p.nphase; ++i) wtaps += p.ph_ntaps[i];
+    const unsigned long long w_b = 4ull * wtaps * p.C * p.Mp;
+    return in_b < 0x7fffffffull && w_b < 0x7fffffffull;
+}
+
+int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes) {
+    fill_sizes(p);
+    if (p.M <= 32) return launch_dma<1, 2, 1, 4>(p, stream, what, ws, ws_bytes);
+    if (p.M <= 64) return launch_dma<2, 1, 1, 4>(p, stream, what, ws, ws_bytes);
+    if (p.M % 96 == 0 || p.M < 96) return launch_dma<3, 1, 1, 4>(p, stream, what, ws, ws_bytes);
+    return launch_dma<2, 2, 2, 2>(p, stream, what, ws, ws_bytes);
+}
+
+int64_t rh_conv_splitk_workspace(ConvP p) {
+    if (p.B <= 0 || p.ncols <= 0 || p.M <= 0 || !rh_conv_dma_eligible(p)) return 0;
+    fill_sizes(p);
+    int64_t want = 0;
+    if (p.M <= 32) launch_dma<1, 2, 1, 4>(p, nullptr, "", nullptr, 0, true, &want);
+    else if (p.M <= 64) launch_dma<2, 1, 1, 4>(p, nullptr, "", nullptr, 0, true, &want);
+    else if (p.M % 96 == 0 || p.M < 96) launch_dma<3, 1, 1, 4>(p, nullptr, "", nullptr, 0, true, &want);
+    else launch_dma<2, 2, 2, 2>(p, nullptr, "", nullptr, 0, true, &want);
+    return want;
+}

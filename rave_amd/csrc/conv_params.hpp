@@ -29,6 +29,15 @@ struct ConvP {
     int wlds_floats;                           // floats reserved for the weight tile in LDS
     int in_act, epi_act;
     float in_slope, epi_slope;
+    // --- LDS-DMA (async global->LDS) pipeline only ---
+    int segs;                                  // 64-float segments per staged input row (pitch = 64*segs)
+    unsigned magic_segs, magic_ck;             // ceil(2^20 / segs), ceil(2^20 / ck): exact n/d for n < 2^15
+    int stage_floats;                          // floats per pipeline stage (weights + input tile)
+    int ksplit;                                // K (channel-chunk) slices; > 1 -> raw partial sums go to `part`
+    int chunks_per_split;
+    float* part;                               // [ksplit][B][M][out_row] scratch (caller workspace)
+    long part_stride;                          // B*M*out_row
+    unsigned in_bytes, w_bytes;                // buffer sizes for the bounds-checked DMA descriptors
     int nphase;
     int ph_oph[kMaxPhases], ph_ntaps[kMaxPhases], ph_tap0[kMaxPhases], ph_minoff[kMaxPhases],
         ph_maxoff[kMaxPhases];
@@ -57,9 +66,18 @@ struct WgradP {
     int ps;                  // LDS pitch of an S row
     int nc_max;              // S rows staged per chunk
     int minoff, maxoff;
+    // --- LDS-DMA pipeline only ---
+    unsigned magic_ps, magic_cpb;   // ceil(2^20/ps), ceil(2^20/chunks_per_b)
+    int r_floats, s_floats;         // flat tile sizes (multiples of 64 floats)
+    int stage_floats;
+    unsigned r_bytes, s_bytes;
     int off[kMaxTaps];
 };
 
 int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p);
 int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p);
-int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what);
+int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what, void* ws = nullptr, int64_t ws_bytes = 0);
+int rh_conv_launch_sync(ConvP& p, hipStream_t stream, const char* what);   // register-staged (all activations)
+int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes);
+bool rh_conv_dma_eligible(const ConvP& p);
+int64_t rh_conv_splitk_workspace(ConvP p);     // bytes of scratch the launch would like (0 = none)

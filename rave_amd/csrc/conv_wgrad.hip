@@ -143,6 +143,165 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if (threadIdx.x == 0) db[m] = red[0];
 }
 
+
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kPR = 65;   // LDS pitch of an R row: 64 reduction elements + 1 (conflict-free column reads)
+// exact n / d for n < 2^32 / d with magic = ceil(2^32 / d) (d >= 2); magic == 0 encodes d == 1
+__device__ __forceinline__ unsigned mdiv(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+
+// Same GEMM as wgrad_kernel, software-pipelined with LDS-DMA: two LDS stages, the DMA engine
+// fills stage (i+1)&1 with the next (batch, position-chunk) tiles of R and S while the matrix
+// cores reduce stage i&1.  Tiles are copied as FLAT arrays (every DMA lane derives its own source
+// element from its LDS position), so row pitches can be odd / tight and overlapping writes are
+// always identical.  Zero padding comes from out-of-range buffer offsets; LeakyReLU of the saved
+// forward input is applied when the operand is read from LDS.
+template <int TM, int TN, int WM, int WN, bool RLEAKY, bool SLEAKY>
+__global__ __launch_bounds__(WM* WN * 64) void wgrad_dma_kernel(const WgradP p) {
+    constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
+    constexpr int NW = WM * WN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int m0 = blockIdx.y * BM, col0 = blockIdx.x * BN, z = blockIdx.z;
+    const int ncols = p.C * p.T;
+    const int inner = p.inner, is = p.is;
+    const int c_lo = col0 / p.T;
+
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
+    const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.S), 0, p.s_bytes, 0x00020000);
+
+    int sb[TN], ar[TM];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int col = col0 + (wn * TN + tn) * 32 + j;
+        col = min(col, ncols - 1);
+        const int c = col / p.T, t = col - c * p.T;
+        sb[tn] = (c - c_lo) * p.ps + (p.off[t] - p.minoff) * inner + kh * is * inner;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) ar[tm] = ((wm * TM + tm) * 32 + j) * kPR + kh * inner;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int r_rows = p.r_row / inner;
+    const int s_width = ((p.rk - 1) * is + (p.maxoff - p.minoff) + 1) * inner;
+    const int r_instrs = p.r_floats >> 6, s_instrs = p.s_floats >> 6;
+
+    auto issue = [&](int ch, float* stage) {
+        const unsigned b = mdiv((unsigned)ch, p.magic_cpb);
+        const int q0 = (ch - (int)b * p.chunks_per_b) * p.rk;
+        const int nk = min(p.rk, r_rows - q0) * inner;
+        const unsigned rb = (b * p.M) * (unsigned)p.r_row + (unsigned)(q0 * inner);
+        for (int q = wave; q < r_instrs; q += NW) {
+            const unsigned pos = (unsigned)q * 64u + lane;
+            const unsigned row = pos / (unsigned)kPR;
+            const unsigned e = pos - row * kPR;
+            const unsigned m = m0 + row;
+            unsigned off = kOOB;
+            if (row < (unsigned)BM && m < (unsigned)p.M && e < (unsigned)nk) off = (rb + m * (unsigned)p.r_row + e) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + q * 64), 4, off, 0, 0, 0);
+        }
+        const int lo = (q0 * is + p.minoff) * inner;
+        const unsigned sbase = (b * p.C) * (unsigned)p.s_row;
+        float* ss = stage + p.r_floats;
+        for (int q = wave; q < s_instrs; q += NW) {
+            const unsigned pos = (unsigned)q * 64u + lane;
+            const unsigned row = mdiv(pos, p.magic_ps);
+            const unsigned e = pos - row * p.ps;
+            const unsigned c = c_lo + row;
+            const int f = lo + (int)e;
+            unsigned off = kOOB;
+            if (row < (unsigned)p.nc_max && c < (unsigned)p.C && e < (unsigned)s_width && f >= 0 && f < p.s_valid)
+                off = (sbase + c * (unsigned)p.s_row + (unsigned)f) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void*)(ss + q * 64), 4, off, 0, 0, 0);
+        }
+    };
+
+    const int ch0 = z * p.chunks_per_z;
+    const int nch = min(p.chunks_per_z, p.total_chunks - ch0);
+    if (nch > 0) issue(ch0, smem);
+    for (int i = 0; i < nch; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (i + 1 < nch) issue(ch0 + i + 1, smem + ((i + 1) & 1) * p.stage_floats);
+        const float* r_lds = smem + (i & 1) * p.stage_floats;
+        const float* s_lds = r_lds + p.r_floats;
+        for (int w = 0; w < inner; ++w) {
+            const float* rl = r_lds + w;
+            const float* sl = s_lds + w;
+            int rr = 0;
+            for (; rr + 8 <= p.rk; rr += 8) {
+                float a[4][TM], bb[4][TN];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        float v = rl[ar[tm] + (rr + 2 * u) * inner];
+                        if (RLEAKY) v = v > 0.f ? v : v * p.r_slope;
+                        a[u][tm] = v;
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = sl[sb[tn] + (rr + 2 * u) * is * inner];
+                        if (SLEAKY) v = v > 0.f ? v : v * p.s_slope;
+                        bb[u][tn] = v;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][tm], bb[u][tn], acc[tm][tn], 0, 0, 0);
+            }
+            for (; rr < p.rk; rr += 2) {
+                float a[TM], bb[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    float v = rl[ar[tm] + rr * inner];
+                    if (RLEAKY) v = v > 0.f ? v : v * p.r_slope;
+                    a[tm] = v;
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    float v = sl[sb[tn] + rr * is * inner];
+                    if (SLEAKY) v = v > 0.f ? v : v * p.s_slope;
+                    bb[tn] = v;
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+    float* out = p.out + (long)z * p.M * ncols;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = col0 + (wn * TN + tn) * 32 + j;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < p.M) out[(long)m * ncols + col] = acc[tm][tn][r];
+            }
+    }
+}
+
 struct WPlan {
     int bm, bn, mt, ct, Z, rk, chunks_per_b, total_chunks, chunks_per_z;
 };
@@ -204,6 +363,8 @@ WPlan plan(const WgradP& p) {
     return w;
 }
 
+inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / (unsigned long long)d); }
+
 template <int TM, int TN, int WM, int WN>
 int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
     constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
@@ -211,6 +372,39 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
     p.chunks_per_b = w.chunks_per_b;
     p.total_chunks = w.total_chunks;
     p.chunks_per_z = w.chunks_per_z;
+    // ---- LDS-DMA pipelined path (LeakyReLU / no activation, tensors < 2 GiB, K chunk <= 64) ----
+    {
+        const unsigned long long rb = 4ull * p.B * p.M * (unsigned long long)p.r_row;
+        const unsigned long long sbytes = 4ull * p.B * p.C * (unsigned long long)p.s_row;
+        const bool ok = p.r_act != RH_ACT_SNAKE && p.s_act != RH_ACT_SNAKE && rb < 0x7fffffffull &&
+                        sbytes < 0x7fffffffull && w.rk * p.inner <= 64 && w.total_chunks < 32768;
+        if (ok) {
+            p.nc_max = (BN - 1) / p.T + 2;
+            if (p.nc_max > p.C) p.nc_max = p.C;
+            p.ps = (((w.rk - 1) * p.is + (p.maxoff - p.minoff) + 1) * p.inner) | 1;
+            p.pr = kPR;
+            p.r_floats = (BM * kPR + 63) & ~63;
+            p.s_floats = (p.nc_max * p.ps + 63) & ~63;
+            p.stage_floats = p.r_floats + p.s_floats;
+            p.magic_ps = magic_of(p.ps);
+            p.magic_cpb = magic_of(w.chunks_per_b);
+            p.r_bytes = (unsigned)rb;
+            p.s_bytes = (unsigned)sbytes;
+            const size_t lds = sizeof(float) * 2 * (size_t)p.stage_floats;
+            if (lds <= 160 * 1024 && (unsigned)p.s_floats < (1u << 15)) {
+                dim3 grid(w.ct, w.mt, w.Z);
+                auto go = [&](auto kern) {
+                    static std::once_flag once;
+                    std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+                    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+                };
+                if (p.r_act == RH_ACT_LEAKY) go(wgrad_dma_kernel<TM, TN, WM, WN, true, false>);
+                else if (p.s_act == RH_ACT_LEAKY) go(wgrad_dma_kernel<TM, TN, WM, WN, false, true>);
+                else go(wgrad_dma_kernel<TM, TN, WM, WN, false, false>);
+                return rh_check_launch("conv1d_bwd_weight(dma)");
+            }
+        }
+    }
     p.pr = (w.rk * p.inner) | 1;
     p.ps = (((w.rk - 1) * p.is + (p.maxoff - p.minoff) + 1) * p.inner) | 1;
     p.nc_max = (BN - 1) / p.T + 2;

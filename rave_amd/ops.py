@@ -94,6 +94,24 @@ def _desc(g: ConvGeom, batch, c_in, c_out, l_in, l_out, k, in_valid=0) -> L.Conv
                       act=g.act, act_slope=g.slope)
 
 
+def _ws(nbytes: int, device) -> Optional[Tensor]:
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes > 0 else None
+
+
+def _fwd(d, x, wp, bias, alpha, residual, y, s):
+    ws = _ws(L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)), y.device)
+    return _launch("conv_fwd", d, lambda: L.lib.rh_conv1d_fwd_f32(
+        C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y),
+        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s))
+
+
+def _dgrad(d, dy, wp, x, alpha, add, dx, s):
+    ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
+    return _launch("conv_dgrad", d, lambda: L.lib.rh_conv1d_bwd_data_f32(
+        C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(dx),
+        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s))
+
+
 def _shapes(x: Tensor, weight: Tensor, g: ConvGeom):
     """Returns (batch, c_in, c_out, l_in, l_out, k, in_valid, out_shape)."""
     k = weight.shape[2]
@@ -143,8 +161,7 @@ class _ConvFn(torch.autograd.Function):
         y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError(f"rave_amd conv: residual shape {tuple(residual.shape)} != output {tuple(y.shape)}")
-        L.check(_launch("conv_fwd", d, lambda: L.lib.rh_conv1d_fwd_f32(
-            dref, L.ptr(x), L.ptr(wp_f), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y), s)), "conv1d_fwd")
+        L.check(_fwd(d, x, wp_f, bias, alpha, residual, y, s), "conv1d_fwd")
         ctx.save_for_backward(x, wp_b, alpha)
         ctx.d = d
         ctx.wshape = tuple(weight.shape)
@@ -162,8 +179,7 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = dalpha = dres = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(_launch("conv_dgrad", d, lambda: L.lib.rh_conv1d_bwd_data_f32(
-                dref, L.ptr(dy), L.ptr(wp_b), L.ptr(x), L.ptr(alpha), None, L.ptr(dx), s)), "conv1d_bwd_data")
+            L.check(_dgrad(d, dy, wp_b, x, alpha, None, dx, s), "conv1d_bwd_data")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
             if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -240,10 +256,8 @@ class _ResidualUnitFn(torch.autograd.Function):
         L.check(L.lib.rh_conv1d_pack_f32(r1, L.ptr(w1), L.ptr(wp1f), L.ptr(wp1b), s), "pack")
         h = torch.empty_like(x)
         y = torch.empty_like(x)
-        L.check(_launch("conv_fwd", d3, lambda: L.lib.rh_conv1d_fwd_f32(
-            r3, L.ptr(x), L.ptr(wp3f), None, L.ptr(alpha0), None, L.ptr(h), s)), "unit k3")
-        L.check(_launch("conv_fwd", d1, lambda: L.lib.rh_conv1d_fwd_f32(
-            r1, L.ptr(h), L.ptr(wp1f), None, L.ptr(alpha2), L.ptr(x), L.ptr(y), s)), "unit k1")
+        L.check(_fwd(d3, x, wp3f, None, alpha0, None, h, s), "unit k3")
+        L.check(_fwd(d1, h, wp1f, None, alpha2, x, y, s), "unit k1")
         ctx.save_for_backward(x, h, wp3b, wp1b, alpha0, alpha2)
         ctx.d3, ctx.d1 = d3, d1
         ctx.w3shape, ctx.w1shape = tuple(w3.shape), tuple(w1.shape)
@@ -260,8 +274,7 @@ class _ResidualUnitFn(torch.autograd.Function):
         if (alpha0 is not None and ctx.needs_input_grad[3]) or (alpha2 is not None and ctx.needs_input_grad[4]):
             raise NotImplementedError("rave_amd: Snake alpha gradient in the fused residual unit")
         dh = torch.empty_like(h)
-        L.check(_launch("conv_dgrad", d1, lambda: L.lib.rh_conv1d_bwd_data_f32(
-            r1, L.ptr(dy), L.ptr(wp1b), L.ptr(h), L.ptr(alpha2), None, L.ptr(dh), s)), "unit k1 dgrad")
+        L.check(_dgrad(d1, dy, wp1b, h, alpha2, None, dh, s), "unit k1 dgrad")
         dw1 = dw3 = dx = None
         n1 = L.lib.rh_conv1d_workspace_bytes(r1)
         n3 = L.lib.rh_conv1d_workspace_bytes(r3)
@@ -277,8 +290,7 @@ class _ResidualUnitFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx = act'(x) * dgrad_k3(dh) + dy   (residual gradient fused as `add`)
-            L.check(_launch("conv_dgrad", d3, lambda: L.lib.rh_conv1d_bwd_data_f32(
-                r3, L.ptr(dh), L.ptr(wp3b), L.ptr(x), L.ptr(alpha0), L.ptr(dy), L.ptr(dx), s)), "unit k3 dgrad")
+            L.check(_dgrad(d3, dh, wp3b, x, alpha0, dy, dx, s), "unit k3 dgrad")
         return dx, dw3, dw1, None, None, None, None
 
 
