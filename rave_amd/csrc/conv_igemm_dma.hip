@@ -9,6 +9,7 @@
 // when the B operand is read from LDS (2 VALU per 64-cycle MFMA group -- free); Snake keeps the
 // register-staged kernel of conv_igemm.hip.  Same math, same accumulation order per output as the
 // synchronous kernel: exact f32, k-ordered fmaf chains.
+#include <cstdlib>
 #include <mutex>
 #include "conv_params.hpp"
 
@@ -274,10 +275,16 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         width = ((bnl - 1) / p.inner + 1) * p.is * p.inner + p.inner + span * p.inner + 1;
     p.segs = rh_cdiv(width, 64);
     p.pitch = p.segs * 64;
-    const int budget = 10 * 1024;  // floats per stage: 2 stages x 40 KiB -> two workgroups per CU
+    static const int budget_env = [] { const char* e = getenv("RH_CONV_STAGE_FLOATS"); return e ? atoi(e) : 0; }();
     const int per_ch = maxtaps * BM + p.nb * p.pitch;
-    int ck = (budget - 256) / per_ch;
-    ck &= ~1;
+    // floats per pipeline stage (2 stages per workgroup): 20 KiB stages give 4 workgroups per CU and
+    // measured best when they still hold >= 8 channels per chunk; otherwise 40 KiB stages (2 per CU)
+    int budget = budget_env > 0 ? budget_env : 5 * 1024;
+    int ck = ((budget - 256) / per_ch) & ~1;
+    if (budget_env <= 0 && ck < 8) {
+        budget = 10 * 1024;
+        ck = ((budget - 256) / per_ch) & ~1;
+    }
     if (ck > 32) ck = 32;
     if (ck < 2) ck = 2;
     const int cmax = (p.C + 1) & ~1;

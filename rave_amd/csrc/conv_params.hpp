@@ -67,7 +67,7 @@ struct WgradP {
     int nc_max;              // S rows staged per chunk
     int minoff, maxoff;
     // --- LDS-DMA pipeline only ---
-    unsigned magic_ps, magic_cpb;   // ceil(2^20/ps), ceil(2^20/chunks_per_b)
+    unsigned magic_ps, magic_cpb, magic_pr;   // ceil(2^32/d) reciprocals (0 encodes d == 1)
     int r_floats, s_floats;         // flat tile sizes (multiples of 64 floats)
     int stage_floats;
     unsigned r_bytes, s_bytes;

@@ -6,6 +6,7 @@
 // The activation of the forward input is re-applied on the fly (the reference keeps a separate
 // activated tensor alive for autograd).  Split-K over (batch, position chunks) with partials in
 // caller-provided scratch and an ordered second pass -> bitwise deterministic.
+#include <cstdlib>
 #include <mutex>
 #include "conv_params.hpp"
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
 
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOOB = 0x80000000u;
-constexpr int kPR = 65;   // LDS pitch of an R row: 64 reduction elements + 1 (conflict-free column reads)
+constexpr int kPR = 65;   // max LDS pitch of an R row: 64 reduction elements + 1 (conflict-free column reads)
 // exact n / d for n < 2^32 / d with magic = ceil(2^32 / d) (d >= 2); magic == 0 encodes d == 1
 __device__ __forceinline__ unsigned mdiv(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
 
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_dma_kernel(const WgradP p) 
         sb[tn] = (c - c_lo) * p.ps + (p.off[t] - p.minoff) * inner + kh * is * inner;
     }
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) ar[tm] = ((wm * TM + tm) * 32 + j) * kPR + kh * inner;
+    for (int tm = 0; tm < TM; ++tm) ar[tm] = ((wm * TM + tm) * 32 + j) * p.pr + kh * inner;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_dma_kernel(const WgradP p) 
         const unsigned rb = (b * p.M) * (unsigned)p.r_row + (unsigned)(q0 * inner);
         for (int q = wave; q < r_instrs; q += NW) {
             const unsigned pos = (unsigned)q * 64u + lane;
-            const unsigned row = pos / (unsigned)kPR;
-            const unsigned e = pos - row * kPR;
+            const unsigned row = mdiv(pos, p.magic_pr);
+            const unsigned e = pos - row * p.pr;
             const unsigned m = m0 + row;
             unsigned off = kOOB;
             if (row < (unsigned)BM && m < (unsigned)p.M && e < (unsigned)nk) off = (rb + m * (unsigned)p.r_row + e) * 4u;
@@ -345,7 +346,10 @@ WPlan plan(const WgradP& p) {
     tile_of(p.M, &w.bm, &w.bn);
     w.mt = rh_cdiv(p.M, w.bm);
     w.ct = rh_cdiv(p.C * p.T, w.bn);
-    int rk = (64 / p.inner) & ~1;
+    static const int rk_env = [] { const char* e = getenv("RH_WGRAD_RK"); return e ? atoi(e) : 0; }();
+    // reduction chunk: 32 positions (3 workgroups per CU) measured best, except pointwise convs
+    // whose S tile has one row per column (64 keeps the DMA instructions full)
+    int rk = ((rk_env > 0 ? rk_env : (p.T == 1 ? 64 : 32)) / p.inner) & ~1;
     if (rk < 2) rk = 2;
     const int r_rows = p.r_row / p.inner;
     if (r_rows < rk) rk = (r_rows + 1) & ~1;  // short sequences: do not pad the K chunk with zeros
@@ -354,7 +358,7 @@ WPlan plan(const WgradP& p) {
     w.chunks_per_b = rh_cdiv(r_rows, rk);
     w.total_chunks = p.B * w.chunks_per_b;
     int Z = 1024 / (w.mt * w.ct);
-    const int zmax = w.total_chunks / 4;
+    const int zmax = w.total_chunks / (rk * p.inner >= 64 ? 8 : 16);   // >= 512 positions per K slice
     if (Z > zmax) Z = zmax;
     if (Z < 1) Z = 1;
     w.chunks_per_z = rh_cdiv(w.total_chunks, Z);
@@ -382,8 +386,9 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
             p.nc_max = (BN - 1) / p.T + 2;
             if (p.nc_max > p.C) p.nc_max = p.C;
             p.ps = (((w.rk - 1) * p.is + (p.maxoff - p.minoff) + 1) * p.inner) | 1;
-            p.pr = kPR;
-            p.r_floats = (BM * kPR + 63) & ~63;
+            p.pr = (w.rk * p.inner) | 1;
+            p.magic_pr = magic_of(p.pr);
+            p.r_floats = (BM * p.pr + 63) & ~63;
             p.s_floats = (p.nc_max * p.ps + 63) & ~63;
             p.stage_floats = p.r_floats + p.s_floats;
             p.magic_ps = magic_of(p.ps);

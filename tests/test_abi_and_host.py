@@ -1,0 +1,101 @@
+"""CPU tests: the C-ABI library loads and exports every symbol declared in include/rave_hip.h (no
+compute calls without a GPU), descriptor-only entry points behave, and the host-side mirrors keep
+the reference's interface (padding rule, state_dict layout, error behaviour)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rave_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rave_amd import _lib as L
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L.lib, n), f"librave_hip.so does not export {n}"
+    assert L.lib.rh_version() >= 100
+
+
+def test_descriptor_queries_and_errors():
+    from rave_amd import _lib as L
+    d = L.ConvDesc(batch=32, c_in=96, c_out=96, l_in=4096, l_out=4096, kernel=3, stride=1, dilation=9,
+                   pad_left=9, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d), 0) == 3 * 96 * 96
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d), 1) == 3 * 96 * 96
+    assert L.lib.rh_conv1d_workspace_bytes(C.byref(d)) > 0
+    assert L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)) == 0            # large grid: no split-K
+    d2 = L.ConvDesc(batch=32, c_in=1536, c_out=256, l_in=32, l_out=32, kernel=3, stride=1, dilation=1,
+                    pad_left=1, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
+    assert L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d2)) > 0            # short sequence: split-K scratch
+    bad = L.ConvDesc(batch=1, c_in=4, c_out=4, l_in=8, l_out=8, kernel=3, stride=1, dilation=1, pad_left=1,
+                     transposed=0, groups=2, inner=1, in_valid=0, act=0, act_slope=0.0)
+    assert L.lib.rh_conv1d_packed_floats(C.byref(bad), 0) == -1            # groups != 1 -> unsupported
+    rc = L.lib.rh_conv1d_pack_f32(C.byref(bad), None, None, None, None)
+    assert rc == -2 and b"groups" in L.lib.rh_last_error()
+    with pytest.raises(RuntimeError):
+        L.check(rc, "pack")
+
+
+def test_get_padding_matches_cached_conv_rule():
+    from rave_amd import cc
+    import rave_oracle as O
+    for k in (1, 2, 3, 4, 7, 8, 15, 33, 513):
+        for d in (1, 3, 9):
+            for mode in ("centered", "causal"):
+                assert cc.get_padding(k, dilation=d, mode=mode) == O.get_padding(k, dilation=d, mode=mode)
+    assert cc.get_padding(513) == (256, 256) and cc.get_padding(33) == (16, 16)
+    cc.set_default_padding_mode("causal")
+    try:
+        assert cc.get_padding(513) == (512, 0)
+        assert cc.get_padding(15, 4, mode="centered") == (7, 7)          # explicit mode wins (discriminator.py:91-97)
+    finally:
+        cc.set_default_padding_mode("centered")
+
+
+def test_module_tree_and_state_dict_match_reference_layout(golden_dir):
+    """Keys and shapes of the drop-in modules == the reference's state_dict (golden fixture)."""
+    from rave_amd import model as M
+    g = torch.load(os.path.join(golden_dir, "v2_tiny.pt"), weights_only=False)
+    c = g["config"]
+    m = M.build_v2(capacity=c["capacity"], latent_size=c["latent_size"])
+    sd = m.state_dict()
+    for k, v in g["state_dict"].items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    extra = set(sd) - set(g["state_dict"])
+    assert extra <= {"receptive_field"}
+    missing, unexpected = m.load_state_dict(g["state_dict"], strict=False)
+    assert not unexpected
+    # attributes scripts/export_onnx.py:34-60 reads
+    conv = m.encoder.encoder.net[0]
+    assert conv._pad == (3, 3) and conv.cumulative_delay == 0 and conv.bias is None
+    assert conv.weight_g.shape == (c["capacity"], 1, 1)
+    up = m.decoder.net[2]
+    assert up.weight_g.shape[0] == up.in_channels          # ConvTranspose: norm over dim 0 = IN channels
+    assert not m.pqmf.forward_conv.weight.requires_grad
+
+
+def test_no_cpu_fallback():
+    from rave_amd import ops
+    g = ops.ConvGeom(pad_left=1, pad_right=1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.conv1d(torch.zeros(1, 4, 8), torch.zeros(4, 4, 3), None, geom=g)
+    with pytest.raises(RuntimeError):
+        ops.pqmf_analysis(torch.zeros(1, 1, 64), torch.zeros(16, 1, 513), (256, 256))
+
+
+def test_streaming_mode_is_refused():
+    from rave_amd import cc
+    cc.use_cached_conv(False)
+    with pytest.raises(NotImplementedError):
+        cc.use_cached_conv(True)
