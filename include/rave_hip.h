@@ -100,6 +100,13 @@ int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which);
 int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd, float* wp_bwd,
                        rh_stream_t stream);
 
+/* Weight norm folded into the repack: v (PyTorch weight layout), g (dim-0 gains) -> norms[r] = ||v[r]||,
+ * scale[r] = g[r]/norms[r] (both `rows` floats, rows = dim 0 of v) and the packed copies of
+ * w = g v/||v||, without materialising w.  Replaces `normalization(cc.Conv1d(...))`
+ * (rave/blocks.py:15-22) on the forward path; the gradient goes through rh_weight_norm_bwd_f32. */
+int rh_conv1d_pack_wn_f32(const rh_conv1d_desc* d, const float* v, const float* g, float* norms,
+                          float* scale, float* wp_fwd, float* wp_bwd, rh_stream_t stream);
+
 /* ---- convolution ---------------------------------------------------------------------- */
 
 /* y = conv(act(x)) + bias + residual.   bias (c_out), residual (B,c_out,l_out*inner) and

@@ -42,6 +42,7 @@ def _load() -> C.CDLL:
         "rh_weight_norm_bwd_f32": ([P, P, P, P, I64, I64, P, P, P], C.c_int),
         "rh_conv1d_packed_floats": ([D, C.c_int], I64),
         "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
+        "rh_conv1d_pack_wn_f32": ([D, P, P, P, P, P, P, P], C.c_int),
         "rh_conv1d_fwd_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_conv1d_bwd_data_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_conv1d_fwd_workspace_bytes": ([D], I64),

@@ -134,8 +134,9 @@ class Residual(nn.Module):
             a0, c3, a2, c1 = unit.net[0], unit.net[1], unit.net[2], unit.net[3]
             f0, f2 = _act_of(a0), _act_of(a2)
             if f0 is not None and f2 is not None and f0[2] is None and f2[2] is None:
-                return ops.residual_unit(x, cc._effective_weight(c3), cc._effective_weight(c1),
-                                         c3.geom(f0[0], f0[1]), c1.geom(f2[0], f2[1]))
+                w3, g3 = cc._wn_pair(c3)
+                w1, g1 = cc._wn_pair(c1)
+                return ops.residual_unit(x, w3, w1, c3.geom(f0[0], f0[1]), c1.geom(f2[0], f2[1]), w3_g=g3, w1_g=g1)
             # Snake: alpha needs its own gradient -> unfused activation, fused residual add
             h = c3(a0(x))
             return c1(a2(h), residual=x)

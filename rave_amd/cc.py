@@ -59,13 +59,22 @@ def get_padding(kernel_size: int, stride: int = 1, dilation: int = 1, mode: Opti
 
 
 def _effective_weight(mod: nn.Module) -> torch.Tensor:
-    """Weight of a (possibly weight-normalised) conv: if ``weight_g``/``weight_v`` exist (registered
-    by rave_amd.blocks.normalization or by torch.nn.utils.weight_norm) the HIP weight-norm kernel
-    recomputes w = g v/||v||, exactly once per forward like the reference (rave/blocks.py:15-22)."""
+    """Materialised weight of a (possibly weight-normalised) conv (rh_weight_norm_fwd_f32)."""
     g = getattr(mod, "weight_g", None)
     if g is not None:
         return ops.weight_norm(mod.weight_v, g)
     return mod.weight
+
+
+def _wn_pair(mod: nn.Module):
+    """(weight, gain) as the fused ops take them: if ``weight_g``/``weight_v`` exist (registered by
+    rave_amd.blocks.normalization or by torch.nn.utils.weight_norm) returns (v, g) and the product
+    g v/||v|| is folded into the weight repack once per forward, like the reference recomputes it
+    once per forward (rave/blocks.py:15-22); otherwise (weight, None)."""
+    g = getattr(mod, "weight_g", None)
+    if g is not None:
+        return mod.weight_v, g
+    return mod.weight, None
 
 
 class Conv1d(nn.Conv1d):
@@ -92,8 +101,8 @@ class Conv1d(nn.Conv1d):
 
     def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, alpha: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None):
-        return ops.conv1d(x, _effective_weight(self), self.bias, geom=self.geom(act, slope),
-                          alpha=alpha, residual=residual)
+        w, g = _wn_pair(self)
+        return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, residual=residual, weight_g=g)
 
 
 class ConvTranspose1d(nn.ConvTranspose1d):
@@ -114,7 +123,8 @@ class ConvTranspose1d(nn.ConvTranspose1d):
                         transposed=True, act=act, slope=slope)
 
     def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, alpha: Optional[torch.Tensor] = None):
-        return ops.conv1d(x, _effective_weight(self), self.bias, geom=self.geom(act, slope), alpha=alpha)
+        w, g = _wn_pair(self)
+        return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, weight_g=g)
 
 
 class PlainConv1d(nn.Conv1d):
@@ -129,7 +139,8 @@ class PlainConv1d(nn.Conv1d):
     def forward(self, x, act: int = ACT_NONE, slope: float = 0.2):
         g = ConvGeom(stride=self.stride[0], dilation=self.dilation[0], pad_left=self.padding[0],
                      pad_right=self.padding[0], act=act, slope=slope)
-        return ops.conv1d(x, _effective_weight(self), self.bias, geom=g)
+        w, wg = _wn_pair(self)
+        return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg)
 
 
 class Conv2dK1(nn.Conv2d):
@@ -150,7 +161,8 @@ class Conv2dK1(nn.Conv2d):
         inner = period if period is not None else x.shape[3]
         g = ConvGeom(stride=self.stride[0], dilation=1, pad_left=self.padding[0], pad_right=self.padding[0],
                      act=act, slope=slope, inner=inner, fold=period is not None)
-        return ops.conv1d(x, _effective_weight(self), self.bias, geom=g)
+        w, wg = _wn_pair(self)
+        return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg)
 
 
 class CachedSequential(nn.Sequential):

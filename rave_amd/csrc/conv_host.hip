@@ -140,16 +140,15 @@ void plan_to_params(const TapPlan& t, ConvP* p) {
 
 struct PackP {
     const float* w;
+    const float* scale;   // per dim-0 slice (weight-norm g/||v||) or null
     float* wp;
-    long total;  // nslots * C * Mp
+    long total;           // nslots * C * Mp
     int C, M, Mp, k;
     int m_major;
     int kk[kMaxTaps];
 };
 
-__global__ __launch_bounds__(256) void pack_kernel(const PackP p) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= p.total) return;
+__device__ __forceinline__ void pack_one_elem(const PackP& p, long e) {
     const int m = (int)(e % p.Mp);
     const long r = e / p.Mp;
     const int c = (int)(r % p.C);
@@ -159,20 +158,41 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackP p) {
         const long src = p.m_major ? ((long)m * p.C + c) * p.k + p.kk[slot]
                                    : ((long)c * p.M + m) * p.k + p.kk[slot];
         v = p.w[src];
+        if (p.scale) v *= p.scale[p.m_major ? m : c];   // dim 0 of the PyTorch weight tensor
     }
     p.wp[e] = v;
 }
 
-int pack_one(const rh_conv1d_desc* d, int which, const float* w, float* wp, hipStream_t stream) {
+// Both packed copies in one launch (forward operand, then data-gradient operand).
+__global__ __launch_bounds__(256) void pack_kernel(const PackP a, const PackP b) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < a.total) pack_one_elem(a, e);
+    else if (e - a.total < b.total) pack_one_elem(b, e - a.total);
+}
+
+int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* scale, float* wp, PackP* p) {
+    *p = PackP{};
+    if (!wp) return RH_OK;
     TapPlan t;
     if (int e = build_plan(d, which, &t)) return e;
-    PackP p{};
-    p.w = w; p.wp = wp; p.C = t.C; p.M = t.M; p.Mp = round32(t.M); p.k = d->kernel;
-    p.m_major = t.src_m_major ? 1 : 0;
-    p.total = (long)t.nslots * t.C * p.Mp;
-    for (int i = 0; i < t.nslots; ++i) p.kk[i] = t.kk[i];
-    if (p.total == 0) return RH_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)rh_cdiv64(p.total, 256)), dim3(256), 0, stream, p);
+    p->w = w; p->scale = scale; p->wp = wp; p->C = t.C; p->M = t.M; p->Mp = round32(t.M); p->k = d->kernel;
+    // dim 0 of the weight tensor is c_out for Conv1d and c_in for ConvTranspose1d:
+    //   which=0: M = c_out. Conv1d -> m_major (dim0 = m);  ConvT -> c-major (dim0 = c)   -> scale index as coded
+    //   which=1: M = c_in.  Conv1d -> c-major (dim0 = c);  ConvT -> m_major (dim0 = m)
+    p->m_major = t.src_m_major ? 1 : 0;
+    p->total = (long)t.nslots * t.C * p->Mp;
+    for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
+    return RH_OK;
+}
+
+int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float* wp_fwd, float* wp_bwd,
+              hipStream_t stream) {
+    PackP a, b;
+    if (int e = fill_pack(d, 0, w, scale, wp_fwd, &a)) return e;
+    if (int e = fill_pack(d, 1, w, scale, wp_bwd, &b)) return e;
+    const long total = a.total + b.total;
+    if (total == 0) return RH_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, a, b);
     return rh_check_launch("conv1d_pack");
 }
 
@@ -229,11 +249,20 @@ extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float
                                   float* wp_bwd, rh_stream_t stream) {
     if (int e = validate(d)) return e;
     RH_REQUIRE(w, RH_ERR_INVALID, "conv1d_pack: null weight");
-    if (wp_fwd)
-        if (int e = pack_one(d, 0, w, wp_fwd, (hipStream_t)stream)) return e;
-    if (wp_bwd)
-        if (int e = pack_one(d, 1, w, wp_bwd, (hipStream_t)stream)) return e;
-    return RH_OK;
+    return pack_both(d, w, nullptr, wp_fwd, wp_bwd, (hipStream_t)stream);
+}
+
+int rh_weight_norm_scales(const float* v, const float* g, int64_t rows, int64_t cols, float* norms, float* scale,
+                          hipStream_t stream);
+
+extern "C" int rh_conv1d_pack_wn_f32(const rh_conv1d_desc* d, const float* v, const float* g, float* norms,
+                                     float* scale, float* wp_fwd, float* wp_bwd, rh_stream_t stream) {
+    if (int e = validate(d)) return e;
+    RH_REQUIRE(v && g && norms && scale, RH_ERR_INVALID, "conv1d_pack_wn: null pointer");
+    const int64_t rows = d->transposed ? d->c_in : d->c_out;
+    const int64_t cols = (int64_t)(d->transposed ? d->c_out : d->c_in) * d->kernel;
+    if (int e = rh_weight_norm_scales(v, g, rows, cols, norms, scale, (hipStream_t)stream)) return e;
+    return pack_both(d, v, scale, wp_fwd, wp_bwd, (hipStream_t)stream);
 }
 
 extern "C" int64_t rh_conv1d_fwd_workspace_bytes(const rh_conv1d_desc* d) {

@@ -67,7 +67,8 @@ struct WgradP {
     int nc_max;              // S rows staged per chunk
     int minoff, maxoff;
     // --- LDS-DMA pipeline only ---
-    unsigned magic_ps, magic_cpb, magic_pr;   // ceil(2^32/d) reciprocals (0 encodes d == 1)
+    unsigned magic_ps, magic_cpb, magic_pr, magic_lpr_r, magic_lpr_s;   // ceil(2^32/d) reciprocals (0 encodes d == 1)
+    int vec;                        // 16-byte DMA fast path enabled
     int r_floats, s_floats;         // flat tile sizes (multiples of 64 floats)
     int stage_floats;
     unsigned r_bytes, s_bytes;

@@ -228,13 +228,64 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_dma_kernel(const WgradP p) 
         }
     };
 
+    // ---- fast path: 16-byte DMA with per-lane source offsets precomputed once ------------------
+    // Each lane owns up to kNI (row, float4) slots of the R tile and of the S tile; per chunk only a
+    // scalar base is added.  Used for chunks whose whole halo lies inside the sequence (no zero
+    // padding inside a float4); boundary chunks take the element-wise path above.
+    constexpr int kNI = 12;
+    unsigned rc[kNI], sc[kNI];
+    int ni_r = 0, ni_s = 0;
+    if (p.vec) {
+        const int lpr_r = p.pr >> 2, lpr_s = p.ps >> 2;
+        const int data_r = p.rk >> 2, data_s = (s_width + 3) >> 2;
+        ni_r = (BM * lpr_r + 64 * NW - 1) / (64 * NW);
+        ni_s = (p.nc_max * lpr_s + 64 * NW - 1) / (64 * NW);
+#pragma unroll
+        for (int i = 0; i < kNI; ++i) {
+            const unsigned g = (unsigned)(wave + NW * i) * 64u + lane;
+            const unsigned rrow = mdiv(g, p.magic_lpr_r);
+            const unsigned rv = g - rrow * lpr_r;
+            rc[i] = (rrow < (unsigned)BM && m0 + rrow < (unsigned)p.M && rv < (unsigned)data_r)
+                        ? (m0 + rrow) * (unsigned)p.r_row + 4u * rv : kOOB;
+            const unsigned srow = mdiv(g, p.magic_lpr_s);
+            const unsigned sv = g - srow * lpr_s;
+            sc[i] = (srow < (unsigned)p.nc_max && c_lo + srow < (unsigned)p.C && sv < (unsigned)data_s)
+                        ? (c_lo + srow) * (unsigned)p.s_row + 4u * sv : kOOB;
+        }
+    }
+    auto issue_any = [&](int ch, float* stage) {
+        if (!p.vec) { issue(ch, stage); return; }
+        const unsigned b = mdiv((unsigned)ch, p.magic_cpb);
+        const int q0 = (ch - (int)b * p.chunks_per_b) * p.rk;
+        const int lo = q0 * is + p.minoff;
+        const bool interior = (q0 + p.rk <= r_rows) && lo >= 0 && lo + 4 * ((s_width + 3) >> 2) <= p.s_valid;
+        if (!interior) { issue(ch, stage); return; }
+        const unsigned rbase = (b * p.M) * (unsigned)p.r_row + (unsigned)q0;
+        const unsigned sbase = (b * p.C) * (unsigned)p.s_row + (unsigned)lo;
+        float* ss = stage + p.r_floats;
+#pragma unroll
+        for (int i = 0; i < kNI; ++i) {
+            if (i < ni_r && (wave + NW * i) * 256 < p.r_floats) {   // never write past the tile's LDS region
+                const unsigned off = rc[i] == kOOB ? kOOB : (rbase + rc[i]) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(stage + (wave + NW * i) * 256), 16, off, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kNI; ++i) {
+            if (i < ni_s && (wave + NW * i) * 256 < p.s_floats) {
+                const unsigned off = sc[i] == kOOB ? kOOB : (sbase + sc[i]) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void*)(ss + (wave + NW * i) * 256), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
     const int ch0 = z * p.chunks_per_z;
     const int nch = min(p.chunks_per_z, p.total_chunks - ch0);
-    if (nch > 0) issue(ch0, smem);
+    if (nch > 0) issue_any(ch0, smem);
     for (int i = 0; i < nch; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (i + 1 < nch) issue(ch0 + i + 1, smem + ((i + 1) & 1) * p.stage_floats);
+        if (i + 1 < nch) issue_any(ch0 + i + 1, smem + ((i + 1) & 1) * p.stage_floats);
         const float* r_lds = smem + (i & 1) * p.stage_floats;
         const float* s_lds = r_lds + p.r_floats;
         for (int w = 0; w < inner; ++w) {
@@ -334,22 +385,27 @@ void fill(const rh_conv1d_desc* d, WgradP* p) {
     p->minoff = lo; p->maxoff = hi;
 }
 
-void tile_of(int M, int* bm, int* bn) {
+void tile_of(int M, int ncols, int* bm, int* bn) {
     if (M <= 32) { *bm = 32; *bn = 256; }
     else if (M <= 64) { *bm = 64; *bn = 128; }
-    else if (M % 96 == 0 || M < 96) { *bm = 96; *bn = 128; }
+    else if (M % 96 == 0 || M < 96) {
+        *bm = 96;
+        // C*T is a multiple of 96 for every 96*2^n-channel layer of v2: 96-wide column tiles (3 waves)
+        // leave no ragged last tile (288 = 3 x 96, not 2 x 128 + 32)
+        *bn = (ncols % 96 == 0 && ncols % 128 != 0) ? 96 : 128;
+    }
     else { *bm = 128; *bn = 128; }
 }
 
 WPlan plan(const WgradP& p) {
     WPlan w{};
-    tile_of(p.M, &w.bm, &w.bn);
+    tile_of(p.M, p.C * p.T, &w.bm, &w.bn);
     w.mt = rh_cdiv(p.M, w.bm);
     w.ct = rh_cdiv(p.C * p.T, w.bn);
     static const int rk_env = [] { const char* e = getenv("RH_WGRAD_RK"); return e ? atoi(e) : 0; }();
     // reduction chunk: 32 positions (3 workgroups per CU) measured best, except pointwise convs
     // whose S tile has one row per column (64 keeps the DMA instructions full)
-    int rk = ((rk_env > 0 ? rk_env : (p.T == 1 ? 64 : 32)) / p.inner) & ~1;
+    int rk = ((rk_env > 0 ? rk_env : 32) / p.inner) & ~1;
     if (rk < 2) rk = 2;
     const int r_rows = p.r_row / p.inner;
     if (r_rows < rk) rk = (r_rows + 1) & ~1;  // short sequences: do not pad the K chunk with zeros
@@ -385,11 +441,28 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
         if (ok) {
             p.nc_max = (BN - 1) / p.T + 2;
             if (p.nc_max > p.C) p.nc_max = p.C;
-            p.ps = (((w.rk - 1) * p.is + (p.maxoff - p.minoff) + 1) * p.inner) | 1;
-            p.pr = (w.rk * p.inner) | 1;
+            const int s_width = ((w.rk - 1) * p.is + (p.maxoff - p.minoff) + 1) * p.inner;
+            static const int novec = [] { const char* e = getenv("RH_WGRAD_NOVEC"); return e ? atoi(e) : 0; }();
+            // 16-byte DMA needs 16-byte aligned rows in LDS (pitches multiple of 4 floats) and in HBM
+            p.vec = !novec && p.inner == 1 && (w.rk % 4) == 0 && (p.r_row % 4) == 0 && (p.s_row % 4) == 0 &&
+                    ((uintptr_t)p.R % 16) == 0 && ((uintptr_t)p.S % 16) == 0;
+            if (p.vec) {
+                p.pr = w.rk + 4;                       // one pad float4 per row: row stride = 4 (mod 32) banks
+                p.ps = ((s_width + 3) & ~3) + 4;
+                if ((p.ps & 31) == 0) p.ps += 4;
+                const int ni_r = rh_cdiv(BM * (p.pr >> 2), 64 * WM * WN);
+                const int ni_s = rh_cdiv(p.nc_max * (p.ps >> 2), 64 * WM * WN);
+                if (ni_r > 12 || ni_s > 12) p.vec = 0;
+            }
+            if (!p.vec) {
+                p.ps = s_width | 1;
+                p.pr = (w.rk * p.inner) | 1;
+            }
             p.magic_pr = magic_of(p.pr);
-            p.r_floats = (BM * p.pr + 63) & ~63;
-            p.s_floats = (p.nc_max * p.ps + 63) & ~63;
+            p.magic_lpr_r = magic_of(p.pr >> 2);
+            p.magic_lpr_s = magic_of(p.ps >> 2);
+            p.r_floats = (BM * p.pr + 255) & ~255;
+            p.s_floats = (p.nc_max * p.ps + 255) & ~255;
             p.stage_floats = p.r_floats + p.s_floats;
             p.magic_ps = magic_of(p.ps);
             p.magic_cpb = magic_of(w.chunks_per_b);
@@ -462,6 +535,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     int e;
     if (w.bm == 32) e = launch_w<1, 2, 1, 4>(p, w, stream);
     else if (w.bm == 64) e = launch_w<2, 1, 1, 4>(p, w, stream);
+    else if (w.bm == 96 && w.bn == 96) e = launch_w<3, 1, 1, 3>(p, w, stream);
     else if (w.bm == 96) e = launch_w<3, 1, 1, 4>(p, w, stream);
     else e = launch_w<2, 2, 2, 2>(p, w, stream);
     if (e) return e;

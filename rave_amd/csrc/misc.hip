@@ -29,6 +29,18 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __res
     if (threadIdx.x == 0 && norms) norms[r] = norm;
 }
 
+// norms[r] = ||v[r,:]||, scale[r] = g[r] / norms[r]  (weight norm folded into the weight repack)
+__global__ __launch_bounds__(256) void weight_norm_scales_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                 long cols, float* __restrict__ norms, float* __restrict__ scale) {
+    __shared__ float red[4];
+    const long r = blockIdx.x;
+    const float* vr = v + r * cols;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < cols; e += 256) { const float a = vr[e]; s += a * a; }
+    const float norm = sqrtf(block_sum(s, red));
+    if (threadIdx.x == 0) { norms[r] = norm; scale[r] = g[r] / norm; }
+}
+
 // dg[r] = <dw, v> / ||v|| ;  dv = (g/||v||) * (dw - v * <dw, v> / ||v||^2)
 __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
                                                               const float* __restrict__ g, const float* __restrict__ norms,
@@ -113,6 +125,13 @@ extern "C" int rh_weight_norm_fwd_f32(const float* v, const float* g, int64_t ro
     hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, v, g,
                        (long)cols, w, norms);
     return rh_check_launch("weight_norm_fwd");
+}
+
+int rh_weight_norm_scales(const float* v, const float* g, int64_t rows, int64_t cols, float* norms, float* scale,
+                          hipStream_t stream) {
+    if (rows == 0) return RH_OK;
+    hipLaunchKernelGGL(weight_norm_scales_kernel, dim3((unsigned)rows), dim3(256), 0, stream, v, g, (long)cols, norms, scale);
+    return rh_check_launch("weight_norm_scales");
 }
 
 extern "C" int rh_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norms,

@@ -141,28 +141,52 @@ def _shapes(x: Tensor, weight: Tensor, g: ConvGeom):
     return b, c_in, c_out, l_in, l_out, k, in_valid, out_shape
 
 
+def _pack(d, w3, g, need_bwd, dev, s):
+    """Packed weight copies for one conv; with ``g`` the weight norm g*v/||v|| is folded into the
+    repack (rh_conv1d_pack_wn_f32).  Returns (wp_fwd, wp_bwd, norms)."""
+    dref = C.byref(d)
+    wp_f = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 0), device=dev, dtype=torch.float32)
+    wp_b = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 1), device=dev, dtype=torch.float32) if need_bwd else None
+    norms = None
+    if g is not None:
+        rows = w3.shape[0]
+        ns = torch.empty(2, rows, device=dev, dtype=torch.float32)
+        norms = ns[0]
+        L.check(L.lib.rh_conv1d_pack_wn_f32(dref, L.ptr(w3), L.ptr(g), L.ptr(ns[0]), L.ptr(ns[1]), L.ptr(wp_f),
+                                            L.ptr(wp_b), s), "conv1d_pack_wn")
+    else:
+        L.check(L.lib.rh_conv1d_pack_f32(dref, L.ptr(w3), L.ptr(wp_f), L.ptr(wp_b), s), "conv1d_pack")
+    return wp_f, wp_b, norms
+
+
+def _wn_bwd(dw, v, g, norms, s):
+    rows = v.shape[0]
+    cols = v.numel() // max(rows, 1)
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g)
+    L.check(L.lib.rh_weight_norm_bwd_f32(L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(norms), rows, cols, L.ptr(dv), L.ptr(dg), s),
+            "weight_norm_bwd")
+    return dv, dg
+
+
 class _ConvFn(torch.autograd.Function):
-    """y = conv(act(x), w) + bias + residual   (rh_conv1d_fwd_f32 and its three gradients)."""
+    """y = conv(act(x), w) + bias + residual, w = weight (g is None) or g*weight/||weight|| (weight norm
+    folded in).  rh_conv1d_fwd_f32 and its gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, alpha, residual, g: ConvGeom):
-        x = _chk(x, "x"); weight = _chk(weight, "weight"); bias = _chk(bias, "bias")
+    def forward(ctx, x, weight, g, bias, alpha, residual, geom: ConvGeom):
+        x = _chk(x, "x"); weight = _chk(weight, "weight"); g = _chk(g, "weight_g"); bias = _chk(bias, "bias")
         alpha = _chk(alpha, "alpha"); residual = _chk(residual, "residual")
         w3 = weight.reshape(weight.shape[0], weight.shape[1], -1) if weight.dim() == 4 else weight
-        b, c_in, c_out, l_in, l_out, k, in_valid, out_shape = _shapes(x, w3, g)
-        d = _desc(g, b, c_in, c_out, l_in, l_out, k, in_valid)
-        dref = C.byref(d)
-        need_dx = ctx.needs_input_grad[0]
-        wp_f = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 0), device=x.device, dtype=torch.float32)
-        wp_b = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 1), device=x.device,
-                           dtype=torch.float32) if need_dx else None
+        b, c_in, c_out, l_in, l_out, k, in_valid, out_shape = _shapes(x, w3, geom)
+        d = _desc(geom, b, c_in, c_out, l_in, l_out, k, in_valid)
         s = L.stream()
-        L.check(L.lib.rh_conv1d_pack_f32(dref, L.ptr(w3), L.ptr(wp_f), L.ptr(wp_b), s), "conv1d_pack")
+        wp_f, wp_b, norms = _pack(d, w3, g, ctx.needs_input_grad[0], x.device, s)
         y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError(f"rave_amd conv: residual shape {tuple(residual.shape)} != output {tuple(y.shape)}")
         L.check(_fwd(d, x, wp_f, bias, alpha, residual, y, s), "conv1d_fwd")
-        ctx.save_for_backward(x, wp_b, alpha)
+        ctx.save_for_backward(x, wp_b, alpha, weight if g is not None else None, g, norms)
         ctx.d = d
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -171,33 +195,39 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, wp_b, alpha = ctx.saved_tensors
+        x, wp_b, alpha, v, g, norms = ctx.saved_tensors
         d = ctx.d
         dref = C.byref(d)
         dy = _chk(dy, "dy")
         s = L.stream()
-        dx = dw = db = dalpha = dres = None
+        dx = dw = dg = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(_dgrad(d, dy, wp_b, x, alpha, None, dx, s), "conv1d_bwd_data")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        need_w = ctx.needs_input_grad[1] or (g is not None and ctx.needs_input_grad[2])
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if need_w or need_b:
             dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if need_b:
                 db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
             L.check(_launch("conv_wgrad", d, lambda: L.lib.rh_conv1d_bwd_weight_f32(
                 dref, L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes, s)), "conv1d_bwd_weight")
-        if alpha is not None and ctx.needs_input_grad[3]:
-            raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.ops.snake + conv")
-        if ctx.has_res and ctx.needs_input_grad[4]:
+            if g is not None:
+                dw, dg = _wn_bwd(dw, v, g, norms, s)
+        if alpha is not None and ctx.needs_input_grad[4]:
+            raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.blocks.Snake + conv")
+        if ctx.has_res and ctx.needs_input_grad[5]:
             dres = dy
-        return dx, dw, db, dalpha, dres, None
+        return dx, dw, dg, db, None, dres, None
 
 
 def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, geom: ConvGeom,
-           alpha: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
-    return _ConvFn.apply(x, weight, bias, alpha, residual, geom)
+           alpha: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+           weight_g: Optional[Tensor] = None) -> Tensor:
+    """``weight_g`` given: ``weight`` is the weight-norm direction v and w = g*v/||v|| (dim 0)."""
+    return _ConvFn.apply(x, weight, weight_g, bias, alpha, residual, geom)
 
 
 class _WeightNormFn(torch.autograd.Function):
@@ -235,67 +265,68 @@ def weight_norm(v: Tensor, g: Tensor) -> Tensor:
 class _ResidualUnitFn(torch.autograd.Function):
     """Residual(DilatedUnit) as ONE autograd node (rave/blocks.py:31-45, 83-112):
         h = conv_k3_dil(act(x), w3);  y = conv_k1(act(h), w1) + x
-    Saves only x and h; activations, padding and the residual add live inside the kernels."""
+    with w = g*v/||v|| folded into the weight repack when g3/g1 are given.  Saves only x and h;
+    activations, padding, weight norm and the residual add live inside the kernels."""
 
     @staticmethod
-    def forward(ctx, x, w3, w1, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom):
-        x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1")
+    def forward(ctx, x, w3, g3w, w1, g1w, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom):
+        x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1"); g3w = _chk(g3w, "g3"); g1w = _chk(g1w, "g1")
         alpha0 = _chk(alpha0, "alpha0"); alpha2 = _chk(alpha2, "alpha2")
         b, c, l = x.shape
         k = w3.shape[2]
         d3 = _desc(g3, b, c, c, l, l, k)
         d1 = _desc(g1, b, c, c, l, l, 1)
-        r3, r1 = C.byref(d3), C.byref(d1)
         s = L.stream()
-        dev = x.device
-        n3 = L.lib.rh_conv1d_packed_floats(r3, 0)
-        n1 = L.lib.rh_conv1d_packed_floats(r1, 0)
-        wp3f = torch.empty(n3, device=dev); wp3b = torch.empty(L.lib.rh_conv1d_packed_floats(r3, 1), device=dev)
-        wp1f = torch.empty(n1, device=dev); wp1b = torch.empty(L.lib.rh_conv1d_packed_floats(r1, 1), device=dev)
-        L.check(L.lib.rh_conv1d_pack_f32(r3, L.ptr(w3), L.ptr(wp3f), L.ptr(wp3b), s), "pack")
-        L.check(L.lib.rh_conv1d_pack_f32(r1, L.ptr(w1), L.ptr(wp1f), L.ptr(wp1b), s), "pack")
+        wp3f, wp3b, n3 = _pack(d3, w3, g3w, True, x.device, s)
+        wp1f, wp1b, n1 = _pack(d1, w1, g1w, True, x.device, s)
         h = torch.empty_like(x)
         y = torch.empty_like(x)
         L.check(_fwd(d3, x, wp3f, None, alpha0, None, h, s), "unit k3")
         L.check(_fwd(d1, h, wp1f, None, alpha2, x, y, s), "unit k1")
-        ctx.save_for_backward(x, h, wp3b, wp1b, alpha0, alpha2)
+        ctx.save_for_backward(x, h, wp3b, wp1b, alpha0, alpha2, w3 if g3w is not None else None, g3w, n3,
+                              w1 if g1w is not None else None, g1w, n1)
         ctx.d3, ctx.d1 = d3, d1
         ctx.w3shape, ctx.w1shape = tuple(w3.shape), tuple(w1.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, h, wp3b, wp1b, alpha0, alpha2 = ctx.saved_tensors
+        x, h, wp3b, wp1b, alpha0, alpha2, v3, g3w, n3, v1, g1w, n1 = ctx.saved_tensors
         d3, d1 = ctx.d3, ctx.d1
         r3, r1 = C.byref(d3), C.byref(d1)
         dy = _chk(dy, "dy")
         s = L.stream()
         dev = dy.device
-        if (alpha0 is not None and ctx.needs_input_grad[3]) or (alpha2 is not None and ctx.needs_input_grad[4]):
+        if (alpha0 is not None and ctx.needs_input_grad[5]) or (alpha2 is not None and ctx.needs_input_grad[6]):
             raise NotImplementedError("rave_amd: Snake alpha gradient in the fused residual unit")
         dh = torch.empty_like(h)
         L.check(_dgrad(d1, dy, wp1b, h, alpha2, None, dh, s), "unit k1 dgrad")
-        dw1 = dw3 = dx = None
-        n1 = L.lib.rh_conv1d_workspace_bytes(r1)
-        n3 = L.lib.rh_conv1d_workspace_bytes(r3)
-        ws = torch.empty(max(n1, n3, 4) // 4, device=dev)
-        if ctx.needs_input_grad[2]:
+        dw1 = dw3 = dg1 = dg3 = dx = None
+        nb1 = L.lib.rh_conv1d_workspace_bytes(r1)
+        nb3 = L.lib.rh_conv1d_workspace_bytes(r3)
+        ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
+        if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
             dw1 = torch.empty(ctx.w1shape, device=dev)
             L.check(_launch("conv_wgrad", d1, lambda: L.lib.rh_conv1d_bwd_weight_f32(
-                r1, L.ptr(dy), L.ptr(h), L.ptr(alpha2), L.ptr(dw1), None, L.ptr(ws), n1, s)), "unit k1 wgrad")
-        if ctx.needs_input_grad[1]:
+                r1, L.ptr(dy), L.ptr(h), L.ptr(alpha2), L.ptr(dw1), None, L.ptr(ws), nb1, s)), "unit k1 wgrad")
+            if g1w is not None:
+                dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s)
+        if ctx.needs_input_grad[1] or (g3w is not None and ctx.needs_input_grad[2]):
             dw3 = torch.empty(ctx.w3shape, device=dev)
             L.check(_launch("conv_wgrad", d3, lambda: L.lib.rh_conv1d_bwd_weight_f32(
-                r3, L.ptr(dh), L.ptr(x), L.ptr(alpha0), L.ptr(dw3), None, L.ptr(ws), n3, s)), "unit k3 wgrad")
+                r3, L.ptr(dh), L.ptr(x), L.ptr(alpha0), L.ptr(dw3), None, L.ptr(ws), nb3, s)), "unit k3 wgrad")
+            if g3w is not None:
+                dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx = act'(x) * dgrad_k3(dh) + dy   (residual gradient fused as `add`)
             L.check(_dgrad(d3, dh, wp3b, x, alpha0, dy, dx, s), "unit k3 dgrad")
-        return dx, dw3, dw1, None, None, None, None
+        return dx, dw3, dg3, dw1, dg1, None, None, None, None
 
 
-def residual_unit(x, w3, w1, g3: ConvGeom, g1: ConvGeom, alpha0=None, alpha2=None) -> Tensor:
-    return _ResidualUnitFn.apply(x, w3, w1, alpha0, alpha2, g3, g1)
+def residual_unit(x, w3, w1, g3: ConvGeom, g1: ConvGeom, alpha0=None, alpha2=None, w3_g=None, w1_g=None) -> Tensor:
+    """``w3_g`` / ``w1_g`` given: w3 / w1 are weight-norm directions (v) and the gains are folded in."""
+    return _ResidualUnitFn.apply(x, w3, w3_g, w1, w1_g, alpha0, alpha2, g3, g1)
 
 
 # --------------------------------------------------------------------------- PQMF

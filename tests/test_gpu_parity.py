@@ -243,6 +243,39 @@ def test_conv2d_k1_period_fold_vs_cpu(dev, ops, period, T, Ci, Co, act):
     assert rel_l2(bg.grad, br.grad) < TOL_OP
 
 
+@pytest.mark.parametrize("kind", ["conv", "convT", "conv2d"])
+def test_conv_with_folded_weight_norm(dev, ops, kind):
+    """normalization(conv) of rave/blocks.py:15-22 with g*v/||v|| folded into the weight repack:
+    outputs and the gradients of x, v, g, bias vs torch._weight_norm + the CPU conv."""
+    g_ = torch.Generator().manual_seed({"conv": 1, "convT": 2, "conv2d": 3}[kind])
+    if kind == "conv":
+        x = torch.randn(2, 24, 100, generator=g_); v = torch.randn(40, 24, 3, generator=g_) * 0.2
+        geom = ops.ConvGeom(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2)
+        ref = lambda xx, ww, bb: O.cc_conv1d(F.leaky_relu(xx, 0.2), ww, bb, 1, 3, (3, 3))
+    elif kind == "convT":
+        x = torch.randn(2, 48, 33, generator=g_); v = torch.randn(48, 24, 8, generator=g_) * 0.2
+        geom = ops.ConvGeom(stride=4, pad_left=2, pad_right=2, transposed=True, act=1, slope=0.2)
+        ref = lambda xx, ww, bb: F.conv_transpose1d(F.leaky_relu(xx, 0.2), ww, bb, 4, 2)
+    else:
+        x = torch.randn(2, 12, 40, 3, generator=g_); v = torch.randn(20, 12, 5, 1, generator=g_) * 0.2
+        geom = ops.ConvGeom(stride=4, pad_left=2, pad_right=2, act=1, slope=0.2, inner=3)
+        ref = lambda xx, ww, bb: F.conv2d(F.leaky_relu(xx, 0.2), ww, bb, (4, 1), (2, 0))
+    gain = torch.rand(v.shape[0], *([1] * (v.dim() - 1)), generator=g_) + 0.5
+    nb = v.shape[1] if kind == "convT" else v.shape[0]
+    b = torch.randn(nb, generator=g_)
+    xr, vr, gr, br = (t.clone().requires_grad_(True) for t in (x, v, gain, b))
+    y_ref = ref(xr, torch._weight_norm(vr, gr, 0), br)
+    cot = torch.randn(y_ref.shape, generator=g_)
+    (y_ref * cot).sum().backward()
+    xg, vg, gg, bg = (t.to(dev).requires_grad_(True) for t in (x, v, gain, b))
+    y = ops.conv1d(xg, vg, bg, geom=geom, weight_g=gg)
+    assert y.shape == y_ref.shape
+    assert rel_l2(y, y_ref) < TOL_OP
+    (y * cot.to(dev)).sum().backward()
+    for a, r in ((xg, xr), (vg, vr), (gg, gr), (bg, br)):
+        assert rel_l2(a.grad, r.grad) < TOL_OP
+
+
 def test_weight_norm_fwd_bwd(dev, ops):
     for shape in [(96, 16, 7), (1536, 768, 4), (24, 1, 5, 1), (7, 3, 1)]:
         v = torch.randn(*shape)
