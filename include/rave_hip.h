@@ -172,6 +172,12 @@ int rh_amp_tanh_bwd_f32(const float* dy, const float* x, int32_t batch, int32_t 
 /* Standalone activation (used where no conv follows). n = total elements, c/l for snake. */
 int rh_act_fwd_f32(const float* x, const float* snake_alpha, int32_t act, float slope,
                    int32_t batch, int32_t c, int32_t l, float* y, rh_stream_t stream);
+/* Snake backward (rave/blocks.py:852-860): dx and dalpha (c floats) from dy, x (B,c,l), alpha (c).
+ * workspace: rh_snake_bwd_workspace_bytes(batch, c) bytes (ordered partial sums -> deterministic). */
+int64_t rh_snake_bwd_workspace_bytes(int32_t batch, int32_t c);
+int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_t batch, int32_t c,
+                     int32_t l, float* dx, float* dalpha, void* workspace, int64_t workspace_bytes,
+                     rh_stream_t stream);
 /* nn.functional.avg_pool1d(x, 2) of MultiScaleDiscriminator (rave/discriminator.py:135). */
 int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
 int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);

@@ -152,8 +152,83 @@ def golden_v2_tiny(causal=False, name="v2_tiny.pt"):
         build_reference_rave("v2", capacity=cap, latent_size=lat, causal=False)
 
 
+def golden_v3_gen_tiny(name="v3_gen_tiny.pt"):
+    """Generator side of configs/v3.gin (Snake activations + AdaIN, which is the identity in training
+    mode) with causal padding and stereo input (BASELINE configs[4] geometry, shrunk): forward
+    products and the parameter gradients under fixed random cotangents at y_raw / y_mb (well
+    conditioned), produced by the reference modules."""
+    cap, lat, n_signal, batch = 6, 8, 8192, 2
+    torch.manual_seed(0)
+    m = build_reference_rave("v3", n_channels=2, capacity=cap, latent_size=lat, causal=True)
+    m.train()
+    with torch.no_grad():   # make the Snake alphas non-trivial
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("alpha"):
+                p_.copy_(0.5 + torch.rand_like(p_))
+    sd = {k: t(v) for k, v in m.state_dict().items() if k.startswith(("pqmf.", "encoder.", "decoder."))}
+    x = O.synthetic_batch(batch, 2, n_signal, seed=5)
+    gen = torch.Generator().manual_seed(77)
+    zp, x_mb = m.encode(x, return_mb=True)
+    eps = torch.randn(zp.shape[0], lat, zp.shape[-1], generator=gen)
+    mean, scale = zp.chunk(2, 1)
+    std = torch.nn.functional.softplus(scale) + 1e-4
+    z = eps * std + mean
+    y_mb = m.decoder(z)
+    y_raw = m.decode(z)
+    c_raw = torch.randn(y_raw.shape, generator=gen)
+    c_mb = torch.randn(y_mb.shape, generator=gen)
+    m.zero_grad(set_to_none=True)
+    torch.autograd.backward([y_raw, y_mb], [c_raw, c_mb])
+    grads = {k: t(p.grad) for k, p in m.named_parameters()
+             if p.grad is not None and k.startswith(("encoder.", "decoder."))}
+    out = dict(config=dict(capacity=cap, latent_size=lat, n_channels=2, causal=True, n_signal=n_signal, batch=batch),
+               state_dict=sd, x=t(x), eps=eps, x_mb=t(x_mb), z_params=t(zp), z=t(z), y_mb=t(y_mb), y_raw=t(y_raw),
+               cot_raw=c_raw, cot_mb=c_mb, grads=grads)
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients")
+    build_reference_rave("v2", capacity=4, latent_size=4, causal=False)   # reset the causal binding
+
+
+def golden_v2_small_tiny(name="v2_small_tiny.pt"):
+    """configs/v2_small.gin (BASELINE configs[0] family): NoiseGeneratorV2 on the decoder.  Forward
+    products of the reference with the uniform noise draw captured (first RNG draw of decoder.forward),
+    plus parameter gradients under fixed cotangents."""
+    cap, lat, n_signal, batch = 6, 8, 8192, 2
+    torch.manual_seed(0)
+    m = build_reference_rave("v2_small", capacity=cap, latent_size=lat)
+    m.train()
+    sd = {k: t(v) for k, v in m.state_dict().items() if k.startswith(("pqmf.", "encoder.", "decoder."))}
+    x = O.synthetic_batch(batch, 1, n_signal, seed=8)
+    gen = torch.Generator().manual_seed(99)
+    zp, x_mb = m.encode(x, return_mb=True)
+    eps = torch.randn(zp.shape[0], lat, zp.shape[-1], generator=gen)
+    mean, scale = zp.chunk(2, 1)
+    z = eps * (torch.nn.functional.softplus(scale) + 1e-4) + mean
+    torch.manual_seed(4321)
+    y_mb = m.decoder(z)
+    # the draw: torch.rand_like(ir) with ir of shape (B, L/8, n_band, 8)
+    l_amp = y_mb.shape[-1] // 8
+    torch.manual_seed(4321)
+    noise = torch.rand(batch, l_amp, 16, 8) * 2 - 1
+    cfg = O.v2_small_config(capacity=cap, latent_size=lat)
+    chk = O.generator_v2(z.detach(), sd, cfg, noise=noise)
+    assert float((chk - y_mb).abs().max()) == 0.0, "captured noise does not reproduce the reference output"
+    y_raw = m.pqmf.inverse(y_mb)
+    c_mb = torch.randn(y_mb.shape, generator=gen)
+    m.zero_grad(set_to_none=True)
+    torch.autograd.backward([y_mb], [c_mb])
+    grads = {k: t(p.grad) for k, p in m.named_parameters()
+             if p.grad is not None and k.startswith(("encoder.", "decoder."))}
+    out = dict(config=dict(capacity=cap, latent_size=lat, n_signal=n_signal, batch=batch), state_dict=sd, x=t(x),
+               eps=eps, z_params=t(zp), z=t(z), noise=noise, y_mb=t(y_mb), y_raw=t(y_raw), cot_mb=c_mb, grads=grads)
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
     golden_v2_tiny(False, "v2_tiny.pt")
     golden_v2_tiny(True, "v2_tiny_causal.pt")
+    golden_v3_gen_tiny()
+    golden_v2_small_tiny()

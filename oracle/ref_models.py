@@ -39,10 +39,14 @@ def build_reference_rave(config="v2", n_channels=1, capacity=None, ratios=None,
 
     act_kwargs = {}
     adain = None
+    unit_defaults = blocks.DilatedUnit.__init__.__defaults__
     if config == "v3":
-        # configs/snake.gin: every activation -> blocks.Snake ; configs/adain.gin
+        # configs/snake.gin: every activation -> blocks.Snake ; configs/adain.gin.  gin binds
+        # blocks.DilatedUnit.activation separately (EncoderV2/GeneratorV2 do not forward theirs):
+        # emulate that binding by swapping the default of DilatedUnit.__init__ during construction.
         act_kwargs = dict(activation=blocks.Snake)
         adain = blocks.AdaptiveInstanceNormalization
+        blocks.DilatedUnit.__init__.__defaults__ = (blocks.Snake,)
 
     enc_kwargs = dict(data_size=n_band, capacity=capacity, ratios=ratios,
                       latent_size=latent_size, n_out=2, kernel_size=3,
@@ -96,6 +100,7 @@ def build_reference_rave(config="v2", n_channels=1, capacity=None, ratios=None,
         update_discriminator_every=update_every,
         n_channels=n_channels, n_bands=n_band,
     )
+    blocks.DilatedUnit.__init__.__defaults__ = unit_defaults
     return model
 
 

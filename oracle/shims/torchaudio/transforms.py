@@ -5,7 +5,7 @@ import torch.nn as nn
 class Spectrogram(nn.Module):
     def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0,
                  window_fn=torch.hann_window, power=2.0, normalized=False,
-                 wkwargs=None, center=True, pad_mode="reflect", onesided=True):
+                 wkwargs=None, center=True, pad_mode="reflect", onesided=True, return_complex=None):
         super().__init__()
         self.n_fft = n_fft
         self.win_length = win_length if win_length is not None else n_fft

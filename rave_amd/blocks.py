@@ -61,14 +61,15 @@ def normalization(module: nn.Module, mode: Optional[str] = None):
 
 
 class Snake(nn.Module):
-    """rave/blocks.py:852-860.  Standalone form (torch ops, differentiable in alpha); convs fuse it."""
+    """rave/blocks.py:852-860 on the HIP Snake kernels (forward, dx and the per-channel dalpha
+    reduction).  Inference-only graphs may instead fuse it into the next conv (ACT_SNAKE)."""
 
     def __init__(self, dim: int) -> None:
         super().__init__()
         self.alpha = nn.Parameter(torch.ones(dim, 1))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return x + (self.alpha + 1e-9).reciprocal() * (self.alpha * x).sin().pow(2)
+        return ops.snake(x, self.alpha)
 
 
 def _act_of(m: nn.Module):
@@ -98,12 +99,25 @@ class AdaptiveInstanceNormalization(nn.Module):
         raise NotImplementedError("rave_amd AdaIN: eval-mode statistics transfer is not on the training hot path")
 
 
+_DILATED_UNIT_ACTIVATION: Optional[Callable[[int], nn.Module]] = None
+
+
+def set_dilated_unit_activation(activation: Optional[Callable[[int], nn.Module]]) -> None:
+    """What ``blocks.DilatedUnit.activation = @blocks.Snake`` (configs/snake.gin) does through gin: the
+    reference's EncoderV2 / GeneratorV2 do NOT forward their own ``activation`` to the units
+    (rave/blocks.py:553-559, 662-669), the units have their own binding."""
+    global _DILATED_UNIT_ACTIVATION
+    _DILATED_UNIT_ACTIVATION = activation
+
+
 class DilatedUnit(nn.Module):
     """rave/blocks.py:83-112: act -> WN(Conv k dil d) -> act -> WN(Conv 1x1)."""
 
     def __init__(self, dim: int, kernel_size: int, dilation: int,
-                 activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2)) -> None:
+                 activation: Optional[Callable[[int], nn.Module]] = None) -> None:
         super().__init__()
+        if activation is None:
+            activation = _DILATED_UNIT_ACTIVATION or (lambda dim: nn.LeakyReLU(.2))
         net = [
             activation(dim),
             normalization(cc.Conv1d(dim, dim, kernel_size=kernel_size, dilation=dilation, bias=False,
@@ -169,6 +183,70 @@ def normalize_dilations(dilations: Union[Sequence[int], Sequence[Sequence[int]]]
     return dilations
 
 
+def mod_sigmoid(x):
+    """rave/core.py:23-24."""
+    return 2 * torch.sigmoid(x) ** 2.3 + 1e-7
+
+
+def amp_to_impulse_response(amp, target_size):
+    """rave/core.py:48-70 (irfft / roll / hann / pad / roll: stock torch + rocFFT, not a conv)."""
+    amp = torch.stack([amp, torch.zeros_like(amp)], -1)
+    amp = torch.view_as_complex(amp)
+    amp = torch.fft.irfft(amp)
+    filter_size = amp.shape[-1]
+    amp = torch.roll(amp, filter_size // 2, -1)
+    win = torch.hann_window(filter_size, dtype=amp.dtype, device=amp.device)
+    amp = amp * win
+    amp = nn.functional.pad(amp, (0, int(target_size) - int(filter_size)))
+    amp = torch.roll(amp, -filter_size // 2, -1)
+    return amp
+
+
+def fft_convolve(signal, kernel):
+    """rave/core.py:72-82."""
+    signal = nn.functional.pad(signal, (0, signal.shape[-1]))
+    kernel = nn.functional.pad(kernel, (kernel.shape[-1], 0))
+    output = torch.fft.irfft(torch.fft.rfft(signal) * torch.fft.rfft(kernel))
+    return output[..., output.shape[-1] // 2:]
+
+
+class NoiseGeneratorV2(nn.Module):
+    """rave/blocks.py:243-292 (configs/v2_small.gin:42-46).  The three strided convolutions
+    (kernel 2r, stride r, pad (r,0), no weight norm) run on the HIP kernels with the LeakyReLU between
+    them fused; the filtered-noise synthesis (irfft / rfft) is FFT work on stock torch + rocFFT."""
+
+    def __init__(self, in_size: int, hidden_size: int, data_size: int, ratios, noise_bands: int,
+                 n_channels: int = 1, activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2)):
+        super().__init__()
+        net = []
+        self.n_channels = n_channels
+        channels = [in_size]
+        channels.extend((len(ratios) - 1) * [hidden_size])
+        channels.append(data_size * noise_bands * n_channels)
+        for i, r in enumerate(ratios):
+            net.append(cc.Conv1d(channels[i], channels[i + 1], 2 * r, padding=(r, 0), stride=r, bias=False))
+            if i != len(ratios) - 1:
+                net.append(activation(channels[i + 1]))
+        self.net = nn.Sequential(*net)
+        self.data_size = data_size
+        self.register_buffer("target_size", torch.tensor(int(np.prod(ratios))).long())
+
+    def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, noise: Optional[torch.Tensor] = None):
+        """``act``: activation of the CALLER fused into the first conv; ``noise`` injects the
+        U(-1,1) draw (parity runs)."""
+        mods = list(self.net)
+        h = mods[0](x, act=act, slope=slope)
+        h = run_fused(nn.Sequential(*mods[1:]), h) if len(mods) > 1 else h
+        amp = mod_sigmoid(h - 5)
+        amp = amp.permute(0, 2, 1)
+        amp = amp.reshape(amp.shape[0], amp.shape[1], self.n_channels * self.data_size, -1)
+        ir = amp_to_impulse_response(amp, self.target_size)
+        if noise is None:
+            noise = torch.rand_like(ir) * 2 - 1
+        out = fft_convolve(noise, ir).permute(0, 2, 1, 3)
+        return out.reshape(out.shape[0], out.shape[1], -1)
+
+
 class EncoderV2(nn.Module):
     """rave/blocks.py:514-596."""
 
@@ -187,8 +265,7 @@ class EncoderV2(nn.Module):
             for d in dils:
                 if adain is not None:
                     net.append(adain(dim=num_channels))
-                net.append(Residual(DilatedUnit(dim=num_channels, kernel_size=kernel_size, dilation=d,
-                                                activation=activation)))
+                net.append(Residual(DilatedUnit(dim=num_channels, kernel_size=kernel_size, dilation=d)))
             net.append(activation(num_channels))
             out_channels = num_channels * r if keep_dim else num_channels * 2
             net.append(normalization(cc.Conv1d(num_channels, out_channels, kernel_size=2 * r, stride=r,
@@ -216,8 +293,6 @@ class GeneratorV2(nn.Module):
                  activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2),
                  adain: Optional[Callable[[int], nn.Module]] = None) -> None:
         super().__init__()
-        if noise_module is not None:
-            raise NotImplementedError("rave_amd.GeneratorV2: noise_module (v2_small) not mirrored yet")
         data_size = n_channels if data_size is None else data_size * n_channels
         dilations_list = normalize_dilations(dilations, ratios)[::-1]
         ratios = ratios[::-1]
@@ -236,22 +311,43 @@ class GeneratorV2(nn.Module):
             for d in dils:
                 if adain is not None:
                     net.append(adain(num_channels))
-                net.append(Residual(DilatedUnit(dim=num_channels, kernel_size=kernel_size, dilation=d,
-                                                activation=activation)))
+                net.append(Residual(DilatedUnit(dim=num_channels, kernel_size=kernel_size, dilation=d)))
         net.append(activation(num_channels))
-        net.append(normalization(cc.Conv1d(num_channels, data_size * 2 if amplitude_modulation else data_size,
-                                           kernel_size=kernel_size * 2 + 1,
-                                           padding=cc.get_padding(kernel_size * 2 + 1), bias=False)))
+        waveform_module = normalization(cc.Conv1d(num_channels, data_size * 2 if amplitude_modulation else data_size,
+                                                  kernel_size=kernel_size * 2 + 1,
+                                                  padding=cc.get_padding(kernel_size * 2 + 1), bias=False))
         self.noise_module = None
         self.waveform_module = None
+        if noise_module is not None:
+            self.waveform_module = waveform_module
+            self.noise_module = noise_module(out_channels, n_channels=n_channels)
+        else:
+            net.append(waveform_module)
         self.net = cc.CachedSequential(*net)
         self.amplitude_modulation = amplitude_modulation
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = run_fused(self.net, x)
+    def forward(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.noise_module is None:
+            x = run_fused(self.net, x)
+            if self.amplitude_modulation:
+                return ops.amp_tanh(x)          # tanh(a * sigmoid(m)), rave/blocks.py:705-711
+            return torch.tanh(x)
+        # rave/blocks.py:696-711 with a noise branch: the last activation of ``net`` feeds BOTH the
+        # noise generator and the waveform conv -> fuse it into both convs instead of materialising it
+        mods = list(self.net)
+        f = _act_of(mods[-1])
+        if f is not None and f[2] is None:
+            h = run_fused(nn.Sequential(*mods[:-1]), x)
+            n = self.noise_module(h, act=f[0], slope=f[1], noise=noise)
+            x = self.waveform_module(h, act=f[0], slope=f[1])
+        else:
+            h = run_fused(self.net, x)
+            n = self.noise_module(h, noise=noise)
+            x = self.waveform_module(h)
         if self.amplitude_modulation:
-            return ops.amp_tanh(x)          # tanh(a * sigmoid(m)), rave/blocks.py:705-711
-        return torch.tanh(x)
+            x, amplitude = x.split(x.shape[1] // 2, 1)
+            x = x * torch.sigmoid(amplitude)
+        return torch.tanh(x + n)
 
     def set_warmed_up(self, state: bool):
         pass

@@ -94,6 +94,39 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
     y[e] = rh_act_apply(x[e], act, slope, al);
 }
 
+// Snake backward (rave/blocks.py:852-860): f = x + sin^2(a x)/(a+eps)
+//   df/dx = 1 + a sin(2 a x)/(a+eps) ;  df/da = x sin(2 a x)/(a+eps) - sin^2(a x)/(a+eps)^2
+// grid (C, S): block (c, s) handles batch items s, s+S, ... of channel c; writes dx and a partial
+// sum of dy*df/da; snake_alpha_reduce_kernel adds the S partials in order (deterministic).
+__global__ __launch_bounds__(256) void snake_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ alpha, int B, int C, long l,
+                                                        float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const float a = alpha[c];
+    const float inv = 1.f / (a + 1e-9f);
+    float acc = 0.f;
+    for (int b = s; b < B; b += S) {
+        const long base = ((long)b * C + c) * l;
+        for (long e = threadIdx.x; e < l; e += 256) {
+            const float xv = x[base + e], g = dy[base + e];
+            const float sn = sinf(a * xv), s2 = sinf(2.f * a * xv);
+            dx[base + e] = g * (1.f + a * s2 * inv);
+            acc += g * (xv * s2 * inv - sn * sn * inv * inv);
+        }
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) part[c * S + s] = tot;
+}
+__global__ __launch_bounds__(256) void snake_alpha_reduce_kernel(const float* __restrict__ part, int C, int S,
+                                                                 float* __restrict__ dalpha) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[c * S + i];
+    dalpha[c] = s;
+}
+
 __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            int l_in, int l_out, long total) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -171,6 +204,32 @@ extern "C" int rh_act_fwd_f32(const float* x, const float* snake_alpha, int32_t 
     hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, snake_alpha, act,
                        slope, c, (long)l, total, y);
     return rh_check_launch("act_fwd");
+}
+
+extern "C" int64_t rh_snake_bwd_workspace_bytes(int32_t batch, int32_t c) {
+    const int S = batch < 32 ? (batch > 0 ? batch : 1) : 32;
+    return (int64_t)c * S * (int64_t)sizeof(float);
+}
+
+extern "C" int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_t batch, int32_t c,
+                                int32_t l, float* dx, float* dalpha, void* workspace, int64_t workspace_bytes,
+                                rh_stream_t stream) {
+    RH_REQUIRE(batch >= 0 && c > 0 && l >= 0, RH_ERR_INVALID, "snake_bwd: bad shape");
+    RH_REQUIRE(dalpha && alpha, RH_ERR_INVALID, "snake_bwd: null pointer");
+    if (batch == 0 || l == 0) {
+        (void)hipMemsetAsync(dalpha, 0, c * sizeof(float), (hipStream_t)stream);
+        return RH_OK;
+    }
+    RH_REQUIRE(dy && x && dx, RH_ERR_INVALID, "snake_bwd: null pointer");
+    const int S = batch < 32 ? batch : 32;
+    RH_REQUIRE(workspace && workspace_bytes >= (int64_t)c * S * (int64_t)sizeof(float), RH_ERR_WORKSPACE,
+               "snake_bwd: workspace too small");
+    hipLaunchKernelGGL(snake_bwd_kernel, dim3(c, S), dim3(256), 0, (hipStream_t)stream, dy, x, alpha, batch, c, (long)l,
+                       dx, (float*)workspace);
+    if (int e = rh_check_launch("snake_bwd")) return e;
+    hipLaunchKernelGGL(snake_alpha_reduce_kernel, dim3(blocks_for(c)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, c, S, dalpha);
+    return rh_check_launch("snake_alpha_reduce");
 }
 
 extern "C" int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream) {

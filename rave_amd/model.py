@@ -194,19 +194,42 @@ class RAVE(nn.Module):
 V2_DILATIONS = [[1, 3, 9], [1, 3, 9], [1, 3, 9], [1, 3]]
 
 
+def build_v2_small(**kw) -> "RAVE":
+    """configs/v2_small.gin: CAPACITY 48, RATIOS [4,2,2,2], NoiseGeneratorV2, discriminator every 2nd step."""
+    d = dict(capacity=48, ratios=(4, 2, 2, 2), noise=True, update_discriminator_every=2)
+    d.update(kw)
+    return build_v2(**d)
+
+
 def build_v2(n_channels: int = 1, capacity: int = 96, ratios=(4, 4, 4, 2), latent_size: int = 128,
              n_band: int = 16, dilations=None, sampling_rate: int = 44100, causal: bool = False,
-             disc_capacity: Optional[int] = None) -> RAVE:
-    """configs/v1.gin + configs/v2.gin transcribed (cf. oracle/ref_models.py for the citations)."""
+             disc_capacity: Optional[int] = None, snake: bool = False, adain: bool = False,
+             noise: bool = False, update_discriminator_every: int = 4) -> RAVE:
+    """configs/v1.gin + configs/v2.gin transcribed (cf. oracle/ref_models.py for the citations).
+    ``snake`` / ``adain`` add the generator-side overlays of configs/v3.gin (snake.gin: every activation
+    -> blocks.Snake; adain.gin: AdaptiveInstanceNormalization before every unit); ``causal`` =
+    configs/causal.gin."""
     cc.set_default_padding_mode("causal" if causal else "centered")
     blocks.set_normalization_mode("weight_norm")
     dil = dilations or V2_DILATIONS
     ratios = list(ratios)
+    extra = {}
+    blocks.set_dilated_unit_activation(blocks.Snake if snake else None)
+    if snake:
+        extra["activation"] = blocks.Snake
+    if adain:
+        extra["adain"] = blocks.AdaptiveInstanceNormalization
     enc = partial(blocks.VariationalEncoder,
                   encoder=partial(blocks.EncoderV2, data_size=n_band, capacity=capacity, ratios=ratios,
-                                  latent_size=latent_size, n_out=2, kernel_size=3, dilations=dil))
+                                  latent_size=latent_size, n_out=2, kernel_size=3, dilations=dil, **extra))
+    if noise:   # configs/v2_small.gin:42-57
+        extra_dec = dict(noise_module=partial(blocks.NoiseGeneratorV2, hidden_size=64, data_size=n_band,
+                                              ratios=[2, 2, 2], noise_bands=32))
+    else:
+        extra_dec = {}
     dec = partial(blocks.GeneratorV2, data_size=n_band, capacity=capacity, ratios=ratios,
-                  latent_size=latent_size, kernel_size=3, dilations=dil, amplitude_modulation=True)
+                  latent_size=latent_size, kernel_size=3, dilations=dil, amplitude_modulation=True, **extra,
+                  **extra_dec)
     common = dict(out_size=1, capacity=disc_capacity or capacity, n_layers=4, stride=4)
     mpd = partial(discriminator.MultiPeriodDiscriminator, periods=[2, 3, 5, 7, 11],
                   convnet=partial(discriminator.ConvNet, conv=nn.Conv2d, kernel_size=(5, 1), **common))
@@ -222,7 +245,8 @@ def build_v2(n_channels: int = 1, capacity: int = 96, ratios=(4, 4, 4, 2), laten
                  gan_loss=losses.hinge_gan, valid_signal_crop=True,
                  feature_matching_fun=partial(losses.mean_difference, norm="L1", relative=True),
                  num_skipped_features=1, audio_distance=dist, multiband_audio_distance=dist,
-                 weights={"feature_matching": 20}, update_discriminator_every=4, n_channels=n_channels,
-                 n_bands=n_band)
+                 weights={"feature_matching": 20}, update_discriminator_every=update_discriminator_every,
+                 n_channels=n_channels, n_bands=n_band)
     cc.set_default_padding_mode("centered")
+    blocks.set_dilated_unit_activation(None)
     return model

@@ -416,6 +416,36 @@ def amp_tanh(x: Tensor) -> Tensor:
     return _AmpTanhFn.apply(x)
 
 
+class _SnakeFn(torch.autograd.Function):
+    """x + sin^2(alpha x)/(alpha + 1e-9), alpha (C,1) learnable (rave/blocks.py:852-860)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = _chk(x, "x"); alpha = _chk(alpha, "alpha")
+        b, c, l = x.shape
+        y = torch.empty_like(x)
+        L.check(L.lib.rh_act_fwd_f32(L.ptr(x), L.ptr(alpha), ACT_SNAKE, 0.0, b, c, l, L.ptr(y), L.stream()), "snake_fwd")
+        ctx.save_for_backward(x, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        b, c, l = x.shape
+        dx = torch.empty_like(x)
+        da = torch.empty_like(alpha)
+        nbytes = L.lib.rh_snake_bwd_workspace_bytes(b, c)
+        ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
+        L.check(L.lib.rh_snake_bwd_f32(L.ptr(dy), L.ptr(x), L.ptr(alpha), b, c, l, L.ptr(dx), L.ptr(da), L.ptr(ws),
+                                       nbytes, L.stream()), "snake_bwd")
+        return dx, da
+
+
+def snake(x: Tensor, alpha: Tensor) -> Tensor:
+    return _SnakeFn.apply(x, alpha)
+
+
 class _AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -23,7 +23,7 @@ def _make_net():
                          nn.LeakyReLU(0.2), nn.Conv1d(8, 2, 1))
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,22 +47,22 @@ def _worker(rank, world, port, overlap, q):
         loss = net(xs).pow(2).mean()
         loss.backward()
         red.finish()
-    q.put((rank, [p.grad.clone() for p in net.parameters()], extra.grad))
+    torch.save((rank, [p.grad.clone() for p in net.parameters()], extra.grad),
+               os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(overlap):
+def _run(overlap, outdir):
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, str(outdir))) for r in range(2)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=120) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=180)
         assert p.exitcode == 0
+    out = [torch.load(os.path.join(str(outdir), f"rank{r}.pt"), weights_only=False) for r in range(2)]
     net = _make_net()
     torch.manual_seed(1)
     x = torch.randn(8, 4, 32)
@@ -74,9 +74,9 @@ def _run(overlap):
             assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-7)
 
 
-def test_grad_reducer_overlapped():
-    _run(True)
+def test_grad_reducer_overlapped(tmp_path):
+    _run(True, tmp_path)
 
 
-def test_grad_reducer_flush_only():
-    _run(False)
+def test_grad_reducer_flush_only(tmp_path):
+    _run(False, tmp_path)

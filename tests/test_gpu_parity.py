@@ -466,6 +466,64 @@ def test_hot_path_backward_with_reference_cotangents(golden_dir, dev, phase):
     assert checked >= (5 if phase == "vae" else 3)
 
 
+def test_v3_generator_side_golden(golden_dir, dev):
+    """configs/v3.gin generator side (Snake activations with learnable alpha, AdaIN = identity in
+    training), causal padding, stereo: HIP modules vs the reference's golden forward products and
+    ALL parameter gradients (122 tensors incl. every Snake alpha) under fixed cotangents."""
+    from rave_amd import model as M
+    g = _load(golden_dir, "v3_gen_tiny.pt")
+    c = g["config"]
+    m = M.build_v2(n_channels=2, capacity=c["capacity"], latent_size=c["latent_size"], causal=True,
+                   snake=True, adain=True)
+    own = m.state_dict()
+    for k, v in g["state_dict"].items():
+        assert k in own and tuple(own[k].shape) == tuple(v.shape), k
+    m.load_state_dict(g["state_dict"], strict=False)
+    m = m.to(dev).train()
+    x = g["x"].to(dev)
+    zp, x_mb = m.encode(x, return_mb=True)
+    z, _ = m.encoder.reparametrize(zp, g["eps"].to(dev))
+    y_mb = m.decoder(z)
+    y_raw = m.decode(z)
+    for a, b in ((x_mb, "x_mb"), (zp, "z_params"), (z, "z"), (y_mb, "y_mb"), (y_raw, "y_raw")):
+        assert a.shape == g[b].shape and rel_l2(a, g[b]) < TOL_E2E, (b, rel_l2(a, g[b]))
+    torch.autograd.backward([y_raw, y_mb], [g["cot_raw"].to(dev), g["cot_mb"].to(dev)])
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k, gref in g["grads"].items():
+        assert named[k].grad is not None, k
+        worst = max(worst, rel_l2(named[k].grad, gref))
+        assert rel_l2(named[k].grad, gref) < 2e-4, (k, rel_l2(named[k].grad, gref))
+    assert worst < 2e-4
+
+
+def test_v2_small_noise_generator_golden(golden_dir, dev):
+    """configs/v2_small.gin (BASELINE configs[0] family) on the HIP modules: encoder, decoder with the
+    NoiseGeneratorV2 branch (its strided convs on the HIP kernels, FFT synthesis on rocFFT), PQMF^-1,
+    and all parameter gradients under the golden cotangent."""
+    from rave_amd import model as M
+    g = _load(golden_dir, "v2_small_tiny.pt")
+    c = g["config"]
+    m = M.build_v2_small(capacity=c["capacity"], latent_size=c["latent_size"])
+    own = m.state_dict()
+    for k, v in g["state_dict"].items():
+        assert k in own and tuple(own[k].shape) == tuple(v.shape), k
+    m.load_state_dict(g["state_dict"], strict=False)
+    m = m.to(dev).train()
+    zp = m.encode(g["x"].to(dev))
+    assert rel_l2(zp, g["z_params"]) < TOL_E2E
+    z, _ = m.encoder.reparametrize(zp, g["eps"].to(dev))
+    y_mb = m.decoder(z, noise=g["noise"].to(dev))
+    assert rel_l2(y_mb, g["y_mb"]) < TOL_E2E
+    y_raw = m.pqmf.inverse(y_mb)
+    assert rel_l2(y_raw, g["y_raw"]) < TOL_E2E
+    torch.autograd.backward([y_mb], [g["cot_mb"].to(dev)])
+    named = dict(m.named_parameters())
+    for k, gref in g["grads"].items():
+        assert named[k].grad is not None, k
+        assert rel_l2(named[k].grad, gref) < 2e-4, (k, rel_l2(named[k].grad, gref))
+
+
 def test_v2_full_size_forward_vs_oracle(dev):
     """BASELINE config 2 geometry (v2, CAPACITY 96, 65536 samples), batch 2: PQMF -> EncoderV2 ->
     reparametrize -> GeneratorV2 -> PQMF^-1 on the GPU vs the CPU oracle; <= 1e-4 relative L2."""

@@ -189,6 +189,44 @@ def test_backward_with_golden_cotangents(golden_dir, phase):
     assert checked >= 3
 
 
+def test_v3_generator_side_golden(golden_dir):
+    """Snake + AdaIN (identity in training) + causal padding + stereo (configs/v3.gin, causal.gin):
+    oracle forward products and every parameter gradient (incl. Snake alphas) vs the reference."""
+    g = _load(golden_dir, "v3_gen_tiny.pt")
+    c = g["config"]
+    cfg = O.v2_config(capacity=c["capacity"], latent_size=c["latent_size"], n_channels=2, causal=True,
+                      activation="snake", adain=True)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and k in g["grads"]) for k, v in g["state_dict"].items()}
+    x_mb = O.pqmf_encode(g["x"], sd["pqmf.forward_conv.weight"], True)
+    zp = O.encoder_v2(x_mb, sd, cfg)
+    z, _ = O.reparametrize(zp, g["eps"])
+    y_mb = O.generator_v2(z, sd, cfg)
+    y_raw = O.pqmf_decode(y_mb, sd["pqmf.inverse_conv.weight"], 2, True)
+    for a, b in ((x_mb, "x_mb"), (zp, "z_params"), (z, "z"), (y_mb, "y_mb"), (y_raw, "y_raw")):
+        assert a.shape == g[b].shape and rel_l2(a, g[b]) < TOL, b
+    torch.autograd.backward([y_raw, y_mb], [g["cot_raw"], g["cot_mb"]])
+    assert len(g["grads"]) > 100
+    for k, gref in g["grads"].items():
+        assert rel_l2(sd[k].grad, gref) < 2e-5, k
+
+
+def test_v2_small_noise_generator_golden(golden_dir):
+    """configs/v2_small.gin: NoiseGeneratorV2 branch of GeneratorV2 (rave/blocks.py:243-292,696-711)."""
+    g = _load(golden_dir, "v2_small_tiny.pt")
+    c = g["config"]
+    cfg = O.v2_small_config(capacity=c["capacity"], latent_size=c["latent_size"])
+    sd = {k: v.clone().requires_grad_(k in g["grads"]) for k, v in g["state_dict"].items()}
+    zp = O.encoder_v2(O.pqmf_encode(g["x"], sd["pqmf.forward_conv.weight"]), sd, cfg)
+    assert rel_l2(zp, g["z_params"]) < TOL
+    z, _ = O.reparametrize(zp, g["eps"])
+    y_mb = O.generator_v2(z, sd, cfg, noise=g["noise"])
+    assert rel_l2(y_mb, g["y_mb"]) < TOL
+    assert rel_l2(O.pqmf_decode(y_mb, sd["pqmf.inverse_conv.weight"], 1), g["y_raw"]) < TOL
+    torch.autograd.backward([y_mb], [g["cot_mb"]])
+    for k, gref in g["grads"].items():
+        assert rel_l2(sd[k].grad, gref) < 2e-5, k
+
+
 def test_init_state_dict_layout_matches_golden(golden_dir):
     g = _load(golden_dir, "v2_tiny.pt")
     c = g["config"]
