@@ -181,12 +181,25 @@ def main():
             a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
         dom = max(agg, key=lambda k: agg[k][3])
         n, fl, by, ms = agg[dom]
+        # HBM traffic per launch of that kernel family from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE / WRITE_SIZE collected in separate runs; see profiles/round1_pmc_traffic.json)
+        traffic, traffic_note = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            fam = "conv_wgrad" if dom == "conv_wgrad" else "conv_igemm(fwd+dgrad)"
+            if args.phase == "vae" and args.batch == 32 and args.n_signal == 65536:
+                traffic = pmc[fam]["hbm_bytes_per_launch"]
+                traffic_note = pmc["_provenance"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {
             "bound": "mfma", "kernel": {"conv_fwd": "conv_igemm_kernel (forward launches)",
                                         "conv_dgrad": "conv_igemm_kernel (data-gradient launches)",
                                         "conv_wgrad": "wgrad_kernel"}[dom],
             "achieved": fl / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": fl / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": None,
+            "frac": fl / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "B per launch",
+            "algorithmic_bytes_per_launch": by / n, "traffic_note": traffic_note,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9,
             "note": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32); HIP events on the launch stream around "
