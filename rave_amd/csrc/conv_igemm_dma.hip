@@ -31,7 +31,7 @@ __device__ __forceinline__ unsigned mdiv(unsigned n, unsigned magic) { return (n
 
 constexpr unsigned kOOB = 0x80000000u;  // >= any descriptor size we accept -> DMA writes zeros
 
-template <int TM, int TN, int WM, int WN, bool LEAKY>
+template <int TM, int TN, int WM, int WN, bool LEAKY, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP p) {
     constexpr int BM = TM * WM * 32;
     constexpr int NW = WM * WN;
@@ -56,9 +56,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
     const int n0 = nt * p.bnl;
     const int m0 = blockIdx.y * BM;
     const int inner = p.inner, is = p.is;
-    const int pitch = p.segs * 64;
+    const int pitch = VEC ? p.pitch : p.segs * 64;
     const int ib0 = ibase_of(n0, inner, is);
-    const int lo = ib0 + minoff * inner;
+    const int lo_raw = ib0 + minoff * inner;
+    // VEC: the tile origin is moved down to a multiple of 4 elements so that (rows being multiples of
+    // 4 elements too) no 16-byte load straddles the start / end of a sequence row or of the buffer
+    const int lo = VEC ? lo_raw - ((lo_raw % 4 + 4) % 4) : lo_raw;
 
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.w_bytes, 0x00020000);
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
         const int bl = col >> p.bnl_shift;
         const int nl = col & (p.bnl - 1);
         const int n = min(n0 + nl, p.ncols - 1);
-        xb[tn] = (bl * p.ck + kh) * pitch + ibase_of(n, inner, is) - ib0;
+        xb[tn] = (bl * p.ck + kh) * pitch + ibase_of(n, inner, is) - ib0 + (lo_raw - lo);
     }
     const int arow = wm * TM * 32 + j + kh * BM;
 
@@ -87,7 +90,80 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
     const int xrows = p.nb * p.ck;
     const int x_instrs = xrows * p.segs;            // 64 floats (64 lanes x 4 B) per DMA instruction
 
+    // ---- VEC: 16-byte DMA, per-lane source offsets precomputed once per workgroup ----------------
+    // Each lane owns up to kNX float4 slots of the input tile and kNWS of the weight tile; per K chunk
+    // only a scalar base is added (the tile's positions never change, only the channel chunk).
+    // Zero padding cannot be produced at float4 granularity, so boundary tiles load whatever lies
+    // next to the sequence (or 0 outside the tensor) and the B operand is masked at read time with
+    // a per-lane bitmask over the taps -- padded positions never reach the matrix cores.
+    constexpr int kNX = 8, kNWS = 10;
+    unsigned xo[VEC ? kNX : 1], xc[VEC ? kNX : 1], wo[VEC ? kNWS : 1], wc[VEC ? kNWS : 1];
+    unsigned long long vm[TN];
+    bool bnd = false;
+    int nx = 0, nws = 0, x_floats = 0;
+    if constexpr (VEC) {
+        const int lpr = pitch >> 2;
+        x_floats = xrows * pitch;
+        nx = (xrows * lpr + 64 * NW - 1) / (64 * NW);
+        nws = (w_instrs + NW - 1) / NW;
+        bnd = lo < 0 || lo + 4 * lpr > p.in_valid;
+#pragma unroll
+        for (int i = 0; i < kNX; ++i) {
+            const unsigned g = (unsigned)(wave + NW * i) * 64u + lane;
+            const unsigned row = mdiv(g, p.magic_lpr);
+            const unsigned v = g - row * lpr;
+            const unsigned bl = mdiv(row, p.magic_ck);
+            const unsigned c = row - bl * p.ck;
+            const bool ok = row < (unsigned)xrows && b0 + bl < (unsigned)p.B;
+            xo[i] = ok ? (bl * p.C + c) * (unsigned)p.in_row + 4u * v : kOOB;
+            xc[i] = c;
+        }
+#pragma unroll
+        for (int i = 0; i < kNWS; ++i) {
+            const unsigned f = ((unsigned)(wave + NW * i) * 64u + lane) * 4u;
+            const unsigned kr = f / (unsigned)BM;
+            const unsigned col = f - kr * BM;
+            const unsigned t = mdiv(kr, p.magic_ck);
+            const unsigned c = kr - t * p.ck;
+            const bool ok = kr < (unsigned)wrows && m0 + col < (unsigned)p.Mp;
+            wo[i] = ok ? (t * p.C + c) * p.Mp + m0 + col : kOOB;
+            wc[i] = c;
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = (wn * TN + tn) * 32 + j;
+            const int nl = col & (p.bnl - 1);
+            const int n = min(n0 + nl, p.ncols - 1);
+            unsigned long long m = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int f = n * is + p.off[tap0 + t];
+                if (f >= 0 && f < p.in_valid) m |= 1ull << t;
+            }
+            vm[tn] = m;
+        }
+    }
+
     auto issue = [&](int c0, float* stage) {
+        if constexpr (VEC) {
+            const unsigned wbase = wofs + (unsigned)c0 * p.Mp;
+#pragma unroll
+            for (int i = 0; i < kNWS; ++i) {
+                if (i < nws && (wave + NW * i) < w_instrs) {
+                    const unsigned off = (wo[i] == kOOB || c0 + wc[i] >= (unsigned)p.C) ? kOOB : (wbase + wo[i]) * 4u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(stage + (wave + NW * i) * 256), 16, off, 0, 0, 0);
+                }
+            }
+            float* xs = stage + p.wlds_floats;
+            const unsigned xbase = ((unsigned)b0 * p.C + (unsigned)c0) * (unsigned)p.in_row + (unsigned)lo;
+#pragma unroll
+            for (int i = 0; i < kNX; ++i) {
+                if (i < nx && (wave + NW * i) * 256 < x_floats) {
+                    const unsigned off = (xo[i] == kOOB || c0 + xc[i] >= (unsigned)p.C) ? kOOB : (xbase + xo[i]) * 4u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)(xs + (wave + NW * i) * 256), 16, off, 0, 0, 0);
+                }
+            }
+            return;
+        }
         // weights: LDS image [tap][c][BM], flat
         for (int q = wave; q < w_instrs; q += NW) {
             const unsigned f = (unsigned)q * 256u + (unsigned)lane * 4u;
@@ -133,6 +209,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
             const int toff = (p.off[tap0 + t] - minoff) * inner;
             const float* wl = w_lds + t * p.ck * BM + arow;
             const float* xl = x_lds + toff;
+            bool keep[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) keep[tn] = !(VEC && bnd) || ((vm[tn] >> t) & 1ull);
             // 4 k-steps (8 channels) per trip: the LDS reads of later steps overlap earlier MFMAs
             int c = 0;
             for (; c + 8 <= p.ck; c += 8) {
@@ -144,6 +223,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         float v = xl[xb[tn] + (c + 2 * u) * pitch];
+                        if (VEC) v = keep[tn] ? v : 0.f;
                         if (LEAKY) v = v > 0.f ? v : v * p.in_slope;
                         b[u][tn] = v;
                     }
@@ -163,6 +243,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     float v = xl[xb[tn] + c * pitch];
+                    if (VEC) v = keep[tn] ? v : 0.f;
                     if (LEAKY) v = v > 0.f ? v : v * p.in_slope;
                     b[tn] = v;
                 }
@@ -273,27 +354,39 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         width = (bnl - 1) * p.is + span + 1;
     else
         width = ((bnl - 1) / p.inner + 1) * p.is * p.inner + p.inner + span * p.inner + 1;
-    p.segs = rh_cdiv(width, 64);
-    p.pitch = p.segs * 64;
+    static const int novec = [] { const char* e = getenv("RH_CONV_NOVEC"); return e ? atoi(e) : 0; }();
+    bool vec = !novec && p.inner == 1 && maxtaps <= 64 && (p.in_row % 4) == 0 && ((uintptr_t)p.in % 16) == 0 &&
+               ((uintptr_t)p.wp % 16) == 0;
     static const int budget_env = [] { const char* e = getenv("RH_CONV_STAGE_FLOATS"); return e ? atoi(e) : 0; }();
-    const int per_ch = maxtaps * BM + p.nb * p.pitch;
-    // floats per pipeline stage (2 stages per workgroup): 20 KiB stages give 4 workgroups per CU and
-    // measured best when they still hold >= 8 channels per chunk; otherwise 40 KiB stages (2 per CU)
-    int budget = budget_env > 0 ? budget_env : 5 * 1024;
-    int ck = ((budget - 256) / per_ch) & ~1;
-    if (budget_env <= 0 && ck < 8) {
-        budget = 10 * 1024;
-        ck = ((budget - 256) / per_ch) & ~1;
+    int ck = 2;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        p.segs = rh_cdiv(width, 64);
+        p.pitch = vec ? ((width + 3 + 3) & ~3) : p.segs * 64;   // +3: origin aligned down to 4 elements
+        const int per_ch = maxtaps * BM + p.nb * p.pitch;
+        // floats per pipeline stage (2 stages per workgroup): 20 KiB stages give 4 workgroups per CU and
+        // measured best when they still hold >= 8 channels per chunk; otherwise 40 KiB stages (2 per CU)
+        int budget = budget_env > 0 ? budget_env : 5 * 1024;
+        ck = ((budget - 512) / per_ch) & ~1;
+        if (budget_env <= 0 && ck < 8) {
+            budget = 10 * 1024;
+            ck = ((budget - 512) / per_ch) & ~1;
+        }
+        if (ck > 32) ck = 32;
+        if (ck < 2) ck = 2;
+        const int cmax = (p.C + 1) & ~1;
+        if (ck > cmax) ck = cmax;
+        if (!vec) break;
+        const int nx = rh_cdiv(p.nb * ck * (p.pitch >> 2), 64 * WM * WN);
+        const int nws = rh_cdiv(rh_cdiv(maxtaps * ck * BM, 256), WM * WN);
+        if (nx <= 8 && nws <= 10) break;
+        vec = false;   // too many DMA slots per lane: use the element-wise variant
     }
-    if (ck > 32) ck = 32;
-    if (ck < 2) ck = 2;
-    const int cmax = (p.C + 1) & ~1;
-    if (ck > cmax) ck = cmax;
     p.ck = ck;
     p.wlds_floats = (maxtaps * ck * BM + 255) & ~255;
-    p.stage_floats = p.wlds_floats + p.nb * ck * p.pitch;
+    p.stage_floats = p.wlds_floats + ((p.nb * ck * p.pitch + 255) & ~255);
     p.magic_segs = magic_of(p.segs);
     p.magic_ck = magic_of(ck);
+    p.magic_lpr = magic_of(p.pitch >> 2);
     const size_t lds = sizeof(float) * 2 * (size_t)p.stage_floats;
     const int col_tiles = rh_cdiv(p.B, p.nb) * p.tiles_per_b;
     Plan pl = plan_split(p, BM, col_tiles);
@@ -315,16 +408,18 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         dim3 grid(col_tiles, rh_cdiv(p.M, BM), p.nphase * p.ksplit);
         hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
     };
-    if (p.in_act == RH_ACT_LEAKY) {
-        auto kern = conv_igemm_dma_kernel<TM, TN, WM, WN, true>;
+    auto go = [&](auto kern) {
         static std::once_flag once;
         std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         launch(kern);
+    };
+    const bool leaky = p.in_act == RH_ACT_LEAKY;
+    if (vec) {
+        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, true>);
+        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, true>);
     } else {
-        auto kern = conv_igemm_dma_kernel<TM, TN, WM, WN, false>;
-        static std::once_flag once;
-        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        launch(kern);
+        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, false>);
+        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, false>);
     }
     if (int e = rh_check_launch(what)) return e;
     if (p.ksplit > 1) {

@@ -31,7 +31,7 @@ struct ConvP {
     float in_slope, epi_slope;
     // --- LDS-DMA (async global->LDS) pipeline only ---
     int segs;                                  // 64-float segments per staged input row (pitch = 64*segs)
-    unsigned magic_segs, magic_ck;             // ceil(2^20 / segs), ceil(2^20 / ck): exact n/d for n < 2^15
+    unsigned magic_segs, magic_ck, magic_lpr;  // ceil(2^20 / d): exact n/d for n*d < 2^20
     int stage_floats;                          // floats per pipeline stage (weights + input tile)
     int ksplit;                                // K (channel-chunk) slices; > 1 -> raw partial sums go to `part`
     int chunks_per_split;
