@@ -11,6 +11,7 @@
 // synchronous kernel: exact f32, k-ordered fmaf chains.
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include "conv_params.hpp"
 
 namespace {
@@ -205,6 +206,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
         if (i + 1 < nchunks) issue((chunk0 + i + 1) * p.ck, smem + ((i + 1) & 1) * p.stage_floats);
         const float* w_lds = smem + (i & 1) * p.stage_floats;
         const float* x_lds = w_lds + p.wlds_floats;
+        // NOTE (measured, round 1): an explicit register ping-pong of the LDS reads (two operand sets,
+        // sched_barrier) cost two waves/SIMD of occupancy and ran 24 % slower (71 -> 54 TFLOP/s over
+        // the v2 layers); four resident waves per SIMD hide the LDS latency better than one wave's ILP.
         for (int t = 0; t < ntaps; ++t) {
             const int toff = (p.off[tap0 + t] - minoff) * inner;
             const float* wl = w_lds + t * p.ck * BM + arow;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
             bool keep[TN];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) keep[tn] = !(VEC && bnd) || ((vm[tn] >> t) & 1ull);
-            // 4 k-steps (8 channels) per trip: the LDS reads of later steps overlap earlier MFMAs
+            // 4 k-steps (8 channels) per trip
             int c = 0;
             for (; c + 8 <= p.ck; c += 8) {
                 float a[4][TM], b[4][TN];
@@ -257,6 +261,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
     }
 
     // ---- epilogue: bias, activation derivative, residual / gradient add ----
+    // Row offsets inside one batch item fit 32 bits (M * out_row < 2^31 is checked on the host);
+    // the per-column base is the only 64-bit quantity.  `full` tiles skip the per-row bound check.
+    const bool full = m0 + BM <= p.M;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int col = (wn * TN + tn) * 32 + j;
@@ -266,25 +273,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
         if (n >= p.ncols || b >= p.B) continue;
         const int oi = oidx_of(n, inner, p.os, oph);
         if (oi >= p.out_valid) continue;
+        const long cbase = (long)b * p.M * p.out_row + oi;
+        float* __restrict__ outp = (p.ksplit > 1 ? p.part + (long)zsl * p.part_stride : p.out) + cbase;
+        const float* __restrict__ mulp = p.mul_src ? p.mul_src + cbase : nullptr;
+        const float* __restrict__ addp = p.add ? p.add + cbase : nullptr;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
+            const int mb = m0 + (wm * TM + tm) * 32 + 4 * kh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < p.M) {
-                    const long idx = ((long)b * p.M + m) * p.out_row + oi;
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (full || m < p.M) {
+                    const int ro = m * p.out_row;
                     float v = acc[tm][tn][r];
                     if (p.ksplit > 1) {
-                        p.part[(long)zsl * p.part_stride + idx] = v;
+                        outp[ro] = v;
                         continue;
                     }
                     if (p.bias) v += p.bias[m];
-                    if (p.mul_src) {
+                    if (mulp) {
                         const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
-                        v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
+                        v *= rh_act_grad(mulp[ro], p.epi_act, p.epi_slope, al);
                     }
-                    if (p.add) v += p.add[idx];
-                    p.out[idx] = v;
+                    if (addp) v += addp[ro];
+                    outp[ro] = v;
                 }
             }
         }
@@ -445,7 +457,8 @@ bool rh_conv_dma_eligible(const ConvP& p) {
     unsigned long long wtaps = 0;
     for (int i = 0; i < p.nphase; ++i) wtaps += p.ph_ntaps[i];
     const unsigned long long w_b = 4ull * wtaps * p.C * p.Mp;
-    return in_b < 0x7fffffffull && w_b < 0x7fffffffull;
+    const unsigned long long row_span = (unsigned long long)p.M * (unsigned long long)p.out_row;
+    return in_b < 0x7fffffffull && w_b < 0x7fffffffull && row_span < 0x7fffffffull;
 }
 
 int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes) {
