@@ -182,6 +182,19 @@ int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_
 int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
 int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);
 
+/* ---- spectral distance ("next" item #1 of SURVEY.md section 8f, beside the hot path) ------------- */
+
+/* AudioDistanceV1 on one STFT scale (rave/core.py:330-344) from two complex spectrograms (interleaved
+ * re,im; n_complex elements each):  sums[0] = sum (|Sx|-|Sy|)^2, sums[1] = sum |Sx|^2,
+ * sums[2] = sum |log(|Sx|+eps) - log(|Sy|+eps)|   =>   distance = sums[0]/sums[1] + sums[2]/n_complex.
+ * The STFT itself stays on rocFFT.  workspace: rh_spectral_distance_workspace_bytes(). */
+int64_t rh_spectral_distance_workspace_bytes(void);
+int rh_spectral_distance_fwd_f32(const float* sx, const float* sy, int64_t n_complex, float eps, float* sums,
+                                 void* workspace, int64_t workspace_bytes, rh_stream_t stream);
+/* d distance / d Sx and / d Sy (either output may be NULL), scaled by the device scalar grad_out[0]. */
+int rh_spectral_distance_bwd_f32(const float* sx, const float* sy, const float* sums, const float* grad_out,
+                                 int64_t n_complex, float eps, float* dsx, float* dsy, rh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,9 @@ def _load() -> C.CDLL:
         "rh_act_fwd_f32": ([P, P, I32, F, I32, I32, I32, P, P], C.c_int),
         "rh_snake_bwd_workspace_bytes": ([I32, I32], I64),
         "rh_snake_bwd_f32": ([P, P, P, I32, I32, I32, P, P, P, I64, P], C.c_int),
+        "rh_spectral_distance_workspace_bytes": ([], I64),
+        "rh_spectral_distance_fwd_f32": ([P, P, I64, F, P, P, I64, P], C.c_int),
+        "rh_spectral_distance_bwd_f32": ([P, P, P, P, I64, F, P, P, P], C.c_int),
         "rh_avgpool2_fwd_f32": ([P, I64, I32, P, P], C.c_int),
         "rh_avgpool2_bwd_f32": ([P, I64, I32, P, P], C.c_int),
     }

@@ -148,6 +148,66 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
 
 inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 
+// ---- spectral distance of AudioDistanceV1 (rave/core.py:330-344) on two complex STFTs -------------
+// a = |Sx|, b = |Sy| ; sums[0] = sum (a-b)^2, sums[1] = sum a^2, sums[2] = sum |log(a+eps) - log(b+eps)|
+// distance = sums[0]/sums[1] + sums[2]/n.  One pass over both spectrograms instead of ~12 elementwise
+// + reduction launches; per-block partials + ordered finalize (deterministic).
+constexpr int kSpecBlocks = 1024;
+
+__global__ __launch_bounds__(256) void spectral_partials_kernel(const float2* __restrict__ sx, const float2* __restrict__ sy,
+                                                                long n, float eps, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float2 x = sx[e], y = sy[e];
+        const float a = sqrtf(x.x * x.x + x.y * x.y), b = sqrtf(y.x * y.x + y.y * y.y);
+        const float d = a - b;
+        s0 += d * d;
+        s1 += a * a;
+        s2 += fabsf(logf(a + eps) - logf(b + eps));
+    }
+    const float t0 = block_sum(s0, red);
+    const float t1 = block_sum(s1, red);
+    const float t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = t0;
+        part[blockIdx.x * 3 + 1] = t1;
+        part[blockIdx.x * 3 + 2] = t2;
+    }
+}
+
+__global__ __launch_bounds__(256) void spectral_finalize_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ sums) {
+    __shared__ float red[4];
+    for (int k = 0; k < 3; ++k) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i * 3 + k];
+        const float t = block_sum(s, red);
+        if (threadIdx.x == 0) sums[k] = t;
+        __syncthreads();
+    }
+}
+
+// gradients w.r.t. both complex spectrograms: d|z|/dz = z/|z| (0 at z = 0, as torch's abs backward)
+__global__ __launch_bounds__(256) void spectral_bwd_kernel(const float2* __restrict__ sx, const float2* __restrict__ sy,
+                                                           const float* __restrict__ sums, const float* __restrict__ gout,
+                                                           long n, float eps, float2* __restrict__ dsx, float2* __restrict__ dsy) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float g = gout[0];
+    const float A = sums[0], B = sums[1];
+    const float invB = 1.f / B, invN = 1.f / (float)n;
+    const float2 x = sx[e], y = sy[e];
+    const float a = sqrtf(x.x * x.x + x.y * x.y), b = sqrtf(y.x * y.x + y.y * y.y);
+    const float d = a - b;
+    const float ld = logf(a + eps) - logf(b + eps);
+    const float sg = ld > 0.f ? 1.f : (ld < 0.f ? -1.f : 0.f);
+    const float da = g * (2.f * d * invB - 2.f * a * A * invB * invB + sg * invN / (a + eps));
+    const float db = g * (-2.f * d * invB - sg * invN / (b + eps));
+    const float ra = a > 0.f ? da / a : 0.f, rb = b > 0.f ? db / b : 0.f;
+    if (dsx) dsx[e] = make_float2(x.x * ra, x.y * ra);
+    if (dsy) dsy[e] = make_float2(y.x * rb, y.y * rb);
+}
+
 }  // namespace
 
 extern "C" int rh_weight_norm_fwd_f32(const float* v, const float* g, int64_t rows, int64_t cols, float* w,
@@ -230,6 +290,31 @@ extern "C" int rh_snake_bwd_f32(const float* dy, const float* x, const float* al
     hipLaunchKernelGGL(snake_alpha_reduce_kernel, dim3(blocks_for(c)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, c, S, dalpha);
     return rh_check_launch("snake_alpha_reduce");
+}
+
+extern "C" int64_t rh_spectral_distance_workspace_bytes(void) { return (int64_t)kSpecBlocks * 3 * (int64_t)sizeof(float); }
+
+extern "C" int rh_spectral_distance_fwd_f32(const float* sx, const float* sy, int64_t n_complex, float eps,
+                                            float* sums, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    RH_REQUIRE(sx && sy && sums && n_complex > 0, RH_ERR_INVALID, "spectral_distance_fwd: bad arguments");
+    RH_REQUIRE(workspace && workspace_bytes >= rh_spectral_distance_workspace_bytes(), RH_ERR_WORKSPACE,
+               "spectral_distance_fwd: workspace too small");
+    long nb = (n_complex + 255) / 256;
+    if (nb > kSpecBlocks) nb = kSpecBlocks;
+    hipLaunchKernelGGL(spectral_partials_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)sx, (const float2*)sy, (long)n_complex, eps, (float*)workspace);
+    if (int e = rh_check_launch("spectral_partials")) return e;
+    hipLaunchKernelGGL(spectral_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                       (int)nb, sums);
+    return rh_check_launch("spectral_finalize");
+}
+
+extern "C" int rh_spectral_distance_bwd_f32(const float* sx, const float* sy, const float* sums, const float* grad_out,
+                                            int64_t n_complex, float eps, float* dsx, float* dsy, rh_stream_t stream) {
+    RH_REQUIRE(sx && sy && sums && grad_out && n_complex > 0, RH_ERR_INVALID, "spectral_distance_bwd: bad arguments");
+    hipLaunchKernelGGL(spectral_bwd_kernel, dim3(blocks_for(n_complex)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)sx, (const float2*)sy, sums, grad_out, (long)n_complex, eps, (float2*)dsx, (float2*)dsy);
+    return rh_check_launch("spectral_bwd");
 }
 
 extern "C" int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream) {

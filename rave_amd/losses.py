@@ -1,8 +1,9 @@
-"""Losses of RAVE.training_step (rave/core.py) -- NOT part of the HIP hot path.
+"""Losses of RAVE.training_step (rave/core.py) -- beside the HIP hot path ("next" #1).
 
-The multi-scale STFT distance runs on stock PyTorch-ROCm (torch.stft -> rocFFT); SURVEY.md section 8f
-ranks a fused STFT-loss kernel as the first "next" item.  Kept here only so that the bench can
-time the complete training step the metric is defined on.
+The STFTs run on stock PyTorch-ROCm (torch.stft -> rocFFT); on the GPU everything after them
+(magnitude, linear + log distance, the three reductions and the whole backward down to the complex
+spectrogram gradients) is ONE fused HIP kernel pair per scale (rh_spectral_distance_{fwd,bwd}_f32).
+The CPU branch keeps the reference's torch formulation and is what the parity tests compare with.
 """
 from __future__ import annotations
 
@@ -46,14 +47,14 @@ class MultiScaleSTFT(nn.Module):
         for s in self.scales:
             self.register_buffer(f"window_{s}", torch.hann_window(s), persistent=False)
 
-    def forward(self, x):
+    def complex_stfts(self, x):
         x = x.reshape(-1, x.shape[-1])
-        out = []
-        for s in self.scales:
-            y = torch.stft(x, s, s // 4, s, window=getattr(self, f"window_{s}"), center=True,
+        return [torch.stft(x, s, s // 4, s, window=getattr(self, f"window_{s}"), center=True,
                            pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
-            out.append(y.abs())
-        return out
+                for s in self.scales]
+
+    def forward(self, x):
+        return [y.abs() for y in self.complex_stfts(x)]
 
 
 class AudioDistanceV1(nn.Module):
@@ -65,6 +66,14 @@ class AudioDistanceV1(nn.Module):
         self.log_epsilon = log_epsilon
 
     def forward(self, x, y):
+        if x.is_cuda:
+            # fused path: magnitude, both distances and their reductions in one HIP kernel per scale
+            # (rh_spectral_distance_*), the STFTs themselves on rocFFT
+            from . import ops
+            distance = 0.
+            for a, b in zip(self.multiscale_stft.complex_stfts(x), self.multiscale_stft.complex_stfts(y)):
+                distance = distance + ops.spectral_distance(a, b, float(self.log_epsilon))
+            return {"spectral_distance": distance}
         stfts_x = self.multiscale_stft(x)
         stfts_y = self.multiscale_stft(y)
         distance = 0.

@@ -446,6 +446,42 @@ def snake(x: Tensor, alpha: Tensor) -> Tensor:
     return _SnakeFn.apply(x, alpha)
 
 
+class _SpectralDistanceFn(torch.autograd.Function):
+    """mean((|Sx|-|Sy|)^2)/mean(|Sx|^2) + mean(|log(|Sx|+eps) - log(|Sy|+eps)|) on complex STFTs."""
+
+    @staticmethod
+    def forward(ctx, sx, sy, eps: float):
+        if not (sx.is_cuda and sy.is_cuda and sx.is_complex() and sy.is_complex() and sx.shape == sy.shape):
+            raise RuntimeError("rave_amd spectral_distance: expects two complex GPU tensors of equal shape")
+        sx = sx.contiguous(); sy = sy.contiguous()
+        n = sx.numel()
+        rx, ry = torch.view_as_real(sx), torch.view_as_real(sy)
+        sums = torch.empty(3, device=sx.device, dtype=torch.float32)
+        nbytes = L.lib.rh_spectral_distance_workspace_bytes()
+        ws = torch.empty(nbytes // 4, device=sx.device, dtype=torch.float32)
+        L.check(L.lib.rh_spectral_distance_fwd_f32(L.ptr(rx), L.ptr(ry), n, eps, L.ptr(sums), L.ptr(ws), nbytes,
+                                                   L.stream()), "spectral_distance_fwd")
+        ctx.save_for_backward(sx, sy, sums)
+        ctx.eps = eps
+        return sums[0] / sums[1] + sums[2] / n
+
+    @staticmethod
+    def backward(ctx, g):
+        sx, sy, sums = ctx.saved_tensors
+        g = g.contiguous().reshape(1).float()
+        dsx = torch.empty_like(sx) if ctx.needs_input_grad[0] else None
+        dsy = torch.empty_like(sy) if ctx.needs_input_grad[1] else None
+        L.check(L.lib.rh_spectral_distance_bwd_f32(
+            L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), L.ptr(sums), L.ptr(g), sx.numel(), ctx.eps,
+            None if dsx is None else torch.view_as_real(dsx).data_ptr(),
+            None if dsy is None else torch.view_as_real(dsy).data_ptr(), L.stream()), "spectral_distance_bwd")
+        return dsx, dsy, None
+
+
+def spectral_distance(sx: Tensor, sy: Tensor, eps: float) -> Tensor:
+    return _SpectralDistanceFn.apply(sx, sy, eps)
+
+
 class _AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -317,6 +317,29 @@ def test_amp_tanh_and_avgpool(dev, ops):
         assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-7)
 
 
+def test_fused_spectral_distance_vs_torch(dev):
+    """rh_spectral_distance_* (AudioDistanceV1 after the STFTs, rave/core.py:330-344) vs the torch
+    formulation on CPU: value at the reference's log_epsilon = 1e-7; gradients w.r.t. both waveforms
+    at a well-conditioned epsilon (at 1e-7 the gradient is ill-conditioned for ANY implementation,
+    see DESIGN.md)."""
+    from functools import partial
+    from rave_amd import losses
+    g = torch.Generator().manual_seed(3)
+    x = O.synthetic_batch(3, 1, 16384, seed=4)
+    y = (x + 0.05 * torch.randn(x.shape, generator=g)).clamp(-1, 1)
+    for eps, check_grad in ((1e-7, False), (1e-2, True)):
+        mk = lambda: losses.AudioDistanceV1(partial(losses.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128]), eps)
+        ref_mod, gpu_mod = mk(), mk().to(dev)
+        xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        d_ref = ref_mod(xr, yr)["spectral_distance"]
+        xg, yg = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+        d = gpu_mod(xg, yg)["spectral_distance"]
+        assert abs(float(d) - float(d_ref)) <= 2e-5 * abs(float(d_ref))
+        if check_grad:
+            d_ref.backward(); d.backward()
+            assert rel_l2(xg.grad, xr.grad) < 2e-4 and rel_l2(yg.grad, yr.grad) < 2e-4
+
+
 def test_residual_unit_fused_vs_oracle(dev, ops):
     from rave_amd import cc
     for (C, L, d, causal) in [(96, 300, 9, False), (24, 64, 3, True), (192, 40, 1, False)]:
