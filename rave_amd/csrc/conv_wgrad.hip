@@ -293,29 +293,32 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_dma_kernel(const WgradP p) 
             const float* sl = s_lds + w;
             int rr = 0;
             for (; rr + 8 <= p.rk; rr += 8) {
+                // all 4 x (TM + TN) LDS reads of the group are issued back to back (sched_barrier keeps
+                // hipcc from re-serialising them into read -> wait -> MFMA), then the 4 x TM x TN MFMAs
                 float a[4][TM], bb[4][TN];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        float v = rl[ar[tm] + (rr + 2 * u) * inner];
-                        if (RLEAKY) v = v > 0.f ? v : v * p.r_slope;
-                        a[u][tm] = v;
-                    }
+                    for (int tm = 0; tm < TM; ++tm) a[u][tm] = rl[ar[tm] + (rr + 2 * u) * inner];
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        float v = sl[sb[tn] + (rr + 2 * u) * is * inner];
-                        if (SLEAKY) v = v > 0.f ? v : v * p.s_slope;
-                        bb[u][tn] = v;
-                    }
+                    for (int tn = 0; tn < TN; ++tn) bb[u][tn] = sl[sb[tn] + (rr + 2 * u) * is * inner];
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        if (RLEAKY) a[u][tm] = a[u][tm] > 0.f ? a[u][tm] : a[u][tm] * p.r_slope;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        if (SLEAKY) bb[u][tn] = bb[u][tn] > 0.f ? bb[u][tn] : bb[u][tn] * p.s_slope;
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][tm], bb[u][tn], acc[tm][tn], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             for (; rr < p.rk; rr += 2) {
                 float a[TM], bb[TN];
@@ -413,8 +416,10 @@ WPlan plan(const WgradP& p) {
     w.rk = rk;
     w.chunks_per_b = rh_cdiv(r_rows, rk);
     w.total_chunks = p.B * w.chunks_per_b;
-    int Z = 1024 / (w.mt * w.ct);
-    const int zmax = w.total_chunks / (rk * p.inner >= 64 ? 8 : 16);   // >= 512 positions per K slice
+    static const int ztarget = [] { const char* e = getenv("RH_WGRAD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    static const int zmin_chunks = [] { const char* e = getenv("RH_WGRAD_MINCHUNKS"); return e ? atoi(e) : 16; }();
+    int Z = ztarget / (w.mt * w.ct);
+    const int zmax = w.total_chunks / (rk * p.inner >= 64 ? zmin_chunks / 2 : zmin_chunks);   // positions per K slice
     if (Z > zmax) Z = zmax;
     if (Z < 1) Z = 1;
     w.chunks_per_z = rh_cdiv(w.total_chunks, Z);
