@@ -103,8 +103,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("RAVE_FORCE_DIST", "0") == "1"   # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from rave_amd import ddp, model as M, ops
@@ -116,8 +118,9 @@ def main():
     gen_opt, dis_opt = m.configure_optimizers()
     m.warmed_up = args.phase == "gan"
     gen_params = list(m.encoder.parameters()) + list(m.decoder.parameters())
-    red_gen = ddp.GradReducer(gen_params) if world > 1 else None
-    red_dis = ddp.GradReducer(list(m.discriminator.parameters())) if world > 1 and m.warmed_up else None
+    use_ddp = world > 1 or force_dist
+    red_gen = ddp.GradReducer(gen_params, force=force_dist) if use_ddp else None
+    red_dis = ddp.GradReducer(list(m.discriminator.parameters()), force=force_dist) if use_ddp and m.warmed_up else None
 
     # synthetic 44.1 kHz waveforms, one shard per rank, resident in HBM
     g = torch.Generator().manual_seed(20250509 + rank)
@@ -129,7 +132,7 @@ def main():
     x = x.clamp(-1, 1).to(dev)
 
     def step(i):
-        if world > 1:
+        if use_ddp:
             dis_step = m.warmed_up and not (i % m.update_discriminator_every)
             red = red_dis if dis_step else red_gen
             red.begin()
@@ -139,7 +142,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +155,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_ddp:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     samples = world * args.batch * args.n_signal * args.steps
@@ -229,7 +232,9 @@ def main():
                                "samples_per_s": args.batch * args.n_signal / t_fwd}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
-    if world > 1:
+    if use_ddp:
+        out["ddp"] = {"allreduce_bytes_per_step": (red_gen.bytes_reduced + (red_dis.bytes_reduced if red_dis else 0))
+                      // max(args.warmup + args.steps, 1), "buckets": len(red_gen.buckets), "backend": "nccl (RCCL)"}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

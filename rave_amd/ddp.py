@@ -39,8 +39,9 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
-                 process_group=None, overlap: bool = True):
+                 process_group=None, overlap: bool = True, force: bool = False):
         self.pg = process_group
+        self.force = force   # run the collectives even with a single rank (smoke-testing the RCCL path)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
         plist = [p for p in params if p.requires_grad]
@@ -68,7 +69,7 @@ class GradReducer:
     # ---- lifecycle of one step
     def begin(self) -> None:
         """Call before backward."""
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or self.force
         for b in self.buckets:
             b.pending = len(b.params)
             b.ready = []
