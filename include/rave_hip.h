@@ -184,6 +184,14 @@ int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, 
 
 /* ---- spectral distance ("next" item #1 of SURVEY.md section 8f, beside the hot path) ------------- */
 
+/* STFT framing of torchaudio.transforms.Spectrogram(center=True, pad_mode="reflect") as used by
+ * MultiScaleSTFT (rave/core.py:269-319): frames (rows, n_frames, n_fft) = window * reflect-padded x,
+ * n_frames = t_len / hop + 1; and its adjoint (gradient w.r.t. x).  The FFT stays on rocFFT. */
+int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
+                          int32_t hop, int32_t n_frames, float* frames, rh_stream_t stream);
+int rh_stft_frame_bwd_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
+                          int32_t hop, int32_t n_frames, float* dx, rh_stream_t stream);
+
 /* AudioDistanceV1 on one STFT scale (rave/core.py:330-344) from two complex spectrograms (interleaved
  * re,im; n_complex elements each):  sums[0] = sum (|Sx|-|Sy|)^2, sums[1] = sum |Sx|^2,
  * sums[2] = sum |log(|Sx|+eps) - log(|Sy|+eps)|   =>   distance = sums[0]/sums[1] + sums[2]/n_complex.

@@ -118,11 +118,18 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_kernel(const WgradP p) {
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               long n, int Z) {
+    // 8 independent running sums keep 8 loads in flight per lane; they are combined in a fixed order,
+    // so the result is still bitwise deterministic.
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < Z; ++z) s += part[(long)z * n + e];
-    out[e] = s;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= Z; z += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part[(long)(z + u) * n + e];
+    }
+    for (; z < Z; ++z) s[0] += part[(long)z * n + e];
+    out[e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // dbias[m] = sum_{b,n} dy[b][m][n]  (one block per channel, fixed reduction order)

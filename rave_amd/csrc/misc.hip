@@ -292,6 +292,76 @@ extern "C" int rh_snake_bwd_f32(const float* dy, const float* x, const float* al
     return rh_check_launch("snake_alpha_reduce");
 }
 
+// ---- STFT framing (centre + reflect pad + window) and its adjoint ---------------------------------
+// frames[r][f][i] = window[i] * x[r][reflect(f*hop + i - n/2)]   (torch.stft(center=True, "reflect")
+// as used by torchaudio.transforms.Spectrogram in rave/core.py:286-292), one pass instead of
+// reflection_pad + strided copy + window multiply.  The FFT itself stays on rocFFT (torch.fft.rfft).
+__device__ __forceinline__ int reflect_idx(int p, int t) { return p < 0 ? -p : (p >= t ? 2 * (t - 1) - p : p); }
+
+__global__ __launch_bounds__(256) void stft_frame_fwd_kernel(const float* __restrict__ x, const float* __restrict__ win,
+                                                             int t_len, int n, int hop, int n_frames, long total,
+                                                             float* __restrict__ frames) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int i = (int)(e % n);
+    const long rf = e / n;
+    const int f = (int)(rf % n_frames);
+    const long r = rf / n_frames;
+    const int p = reflect_idx(f * hop + i - n / 2, t_len);
+    frames[e] = win[i] * x[r * t_len + p];
+}
+
+// dx[r][p] = sum over padded coordinates q that reflect onto p of sum_f window[q - f hop] dframes[r][f][q - f hop]
+__global__ __launch_bounds__(256) void stft_frame_bwd_kernel(const float* __restrict__ dfr, const float* __restrict__ win,
+                                                             int t_len, int n, int hop, int n_frames, long total,
+                                                             float* __restrict__ dx) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int p = (int)(e % t_len);
+    const long r = e / t_len;
+    const float* base = dfr + r * (long)n_frames * n;
+    const int half = n / 2;
+    int qs[3];
+    int nq = 0;
+    qs[nq++] = p + half;
+    if (p >= 1 && p <= half) qs[nq++] = half - p;                                   // left reflection
+    if (p <= t_len - 2 && p >= t_len - 1 - half) qs[nq++] = 2 * (t_len - 1) - p + half;   // right reflection
+    float s = 0.f;
+    for (int k = 0; k < nq; ++k) {
+        const int q = qs[k];
+        int f_hi = q / hop;
+        if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+        for (int f = f_hi; f >= 0; --f) {
+            const int i = q - f * hop;
+            if (i >= n) break;
+            s += win[i] * base[(long)f * n + i];
+        }
+    }
+    dx[e] = s;
+}
+
+extern "C" int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
+                                     int32_t hop, int32_t n_frames, float* frames, rh_stream_t stream) {
+    RH_REQUIRE(x && window && frames, RH_ERR_INVALID, "stft_frame_fwd: null pointer");
+    RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_fwd: bad geometry");
+    const long total = rows * (long)n_frames * n_fft;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(stft_frame_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, window, t_len,
+                       n_fft, hop, n_frames, total, frames);
+    return rh_check_launch("stft_frame_fwd");
+}
+
+extern "C" int rh_stft_frame_bwd_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len,
+                                     int32_t n_fft, int32_t hop, int32_t n_frames, float* dx, rh_stream_t stream) {
+    RH_REQUIRE(dframes && window && dx, RH_ERR_INVALID, "stft_frame_bwd: null pointer");
+    RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_bwd: bad geometry");
+    const long total = rows * (long)t_len;
+    if (total <= 0) return RH_OK;
+    hipLaunchKernelGGL(stft_frame_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dframes, window,
+                       t_len, n_fft, hop, n_frames, total, dx);
+    return rh_check_launch("stft_frame_bwd");
+}
+
 extern "C" int64_t rh_spectral_distance_workspace_bytes(void) { return (int64_t)kSpecBlocks * 3 * (int64_t)sizeof(float); }
 
 extern "C" int rh_spectral_distance_fwd_f32(const float* sx, const float* sy, int64_t n_complex, float eps,

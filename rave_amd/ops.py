@@ -446,6 +446,36 @@ def snake(x: Tensor, alpha: Tensor) -> Tensor:
     return _SnakeFn.apply(x, alpha)
 
 
+class _StftFrameFn(torch.autograd.Function):
+    """(rows, T) -> (rows, T//hop + 1, n_fft): centre + reflect pad + window, and the adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, window, n_fft: int, hop: int):
+        x = _chk(x, "x"); window = _chk(window, "window")
+        rows, t = x.shape
+        nf = t // hop + 1
+        frames = torch.empty(rows, nf, n_fft, device=x.device, dtype=torch.float32)
+        L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(x), L.ptr(window), rows, t, n_fft, hop, nf, L.ptr(frames), L.stream()),
+                "stft_frame_fwd")
+        ctx.save_for_backward(window)
+        ctx.geo = (rows, t, n_fft, hop, nf)
+        return frames
+
+    @staticmethod
+    def backward(ctx, dfr):
+        (window,) = ctx.saved_tensors
+        rows, t, n_fft, hop, nf = ctx.geo
+        dfr = _chk(dfr, "dframes")
+        dx = torch.empty(rows, t, device=dfr.device, dtype=torch.float32)
+        L.check(L.lib.rh_stft_frame_bwd_f32(L.ptr(dfr), L.ptr(window), rows, t, n_fft, hop, nf, L.ptr(dx), L.stream()),
+                "stft_frame_bwd")
+        return dx, None, None, None
+
+
+def stft_frames(x: Tensor, window: Tensor, n_fft: int, hop: int) -> Tensor:
+    return _StftFrameFn.apply(x, window, n_fft, hop)
+
+
 class _SpectralDistanceFn(torch.autograd.Function):
     """mean((|Sx|-|Sy|)^2)/mean(|Sx|^2) + mean(|log(|Sx|+eps) - log(|Sy|+eps)|) on complex STFTs."""
 

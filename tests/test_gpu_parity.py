@@ -317,6 +317,27 @@ def test_amp_tanh_and_avgpool(dev, ops):
         assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-7)
 
 
+def test_stft_framing_matches_torch_stft(dev):
+    """rh_stft_frame_* + rocFFT rfft == torch.stft(center=True, reflect, Hann) and same input gradient."""
+    from rave_amd import ops as _ops
+    g = torch.Generator().manual_seed(5)
+    for (rows, T, n) in [(3, 4096, 2048), (2, 1000, 128), (4, 300, 256)]:
+        x = torch.randn(rows, T, generator=g)
+        w = torch.hann_window(n)
+        xr = x.clone().requires_grad_(True)
+        ref = torch.stft(xr, n, n // 4, n, window=w, center=True, pad_mode="reflect", normalized=False,
+                         onesided=True, return_complex=True)
+        cot = torch.randn(ref.shape, generator=g, dtype=torch.float32) + 1j * torch.randn(ref.shape, generator=g)
+        (torch.view_as_real(ref) * torch.view_as_real(cot)).sum().backward()
+        xg = x.to(dev).requires_grad_(True)
+        fr = _ops.stft_frames(xg, w.to(dev), n, n // 4)
+        spec = torch.fft.rfft(fr, dim=-1).transpose(-1, -2)
+        assert spec.shape == ref.shape
+        assert rel_l2(torch.view_as_real(spec), torch.view_as_real(ref)) < 1e-5
+        (torch.view_as_real(spec) * torch.view_as_real(cot.to(dev))).sum().backward()
+        assert rel_l2(xg.grad, xr.grad) < 1e-5
+
+
 def test_fused_spectral_distance_vs_torch(dev):
     """rh_spectral_distance_* (AudioDistanceV1 after the STFTs, rave/core.py:330-344) vs the torch
     formulation on CPU: value at the reference's log_epsilon = 1e-7; gradients w.r.t. both waveforms
