@@ -225,6 +225,40 @@ def golden_v2_small_tiny(name="v2_small_tiny.pt"):
     print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients")
 
 
+def golden_v1_tiny(name="v1_tiny.pt"):
+    """configs/v1.gin generator side: v1 Encoder (BatchNorm1d in training mode, grouped head conv),
+    Generator (UpsampleLayer / ResidualStack, waveform x loudness, NoiseGenerator once warmed up).
+    Forward products (noise draw captured) and parameter gradients under a fixed cotangent."""
+    cap, lat, n_signal, batch = 4, 8, 8192, 3
+    torch.manual_seed(0)
+    m = build_reference_rave("v1", capacity=cap, latent_size=lat)
+    m.train()
+    sd = {k: t(v) for k, v in m.state_dict().items() if k.startswith(("pqmf.", "encoder.", "decoder."))}
+    x = O.synthetic_batch(batch, 1, n_signal, seed=12)
+    gen = torch.Generator().manual_seed(123)
+    zp, x_mb = m.encode(x, return_mb=True)
+    eps = torch.randn(zp.shape[0], lat, zp.shape[-1], generator=gen)
+    mean, scale = zp.chunk(2, 1)
+    z = eps * (torch.nn.functional.softplus(scale) + 1e-4) + mean
+    y_cold = m.decoder(z)                                  # warmed_up == 0: no noise branch
+    m.decoder.set_warmed_up(True)
+    torch.manual_seed(999)
+    y_warm = m.decoder(z)
+    l_amp = y_warm.shape[-1] // 64                         # NoiseGenerator ratios [4,4,4]
+    torch.manual_seed(999)
+    noise = torch.rand(batch, l_amp, 16, 64) * 2 - 1
+    c_mb = torch.randn(y_warm.shape, generator=gen)
+    m.zero_grad(set_to_none=True)
+    torch.autograd.backward([y_warm], [c_mb])
+    grads = {k: t(p.grad) for k, p in m.named_parameters()
+             if p.grad is not None and k.startswith(("encoder.", "decoder."))}
+    out = dict(config=dict(capacity=cap, latent_size=lat, n_signal=n_signal, batch=batch), state_dict=sd, x=t(x),
+               eps=eps, z_params=t(zp), z=t(z), y_cold=t(y_cold), y_warm=t(y_warm), noise=noise, cot_mb=c_mb,
+               grads=grads)
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients", tuple(noise.shape))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
@@ -232,3 +266,4 @@ if __name__ == "__main__":
     golden_v2_tiny(True, "v2_tiny_causal.pt")
     golden_v3_gen_tiny()
     golden_v2_small_tiny()
+    golden_v1_tiny()

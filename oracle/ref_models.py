@@ -24,6 +24,30 @@ def build_reference_rave(config="v2", n_channels=1, capacity=None, ratios=None,
     from rave import blocks, core, discriminator, pqmf
     set_causal(causal)
 
+    if config == "v1":
+        # configs/v1.gin
+        capacity = capacity or 64
+        ratios = ratios or [4, 4, 4, 2]
+        import gin
+        enc = partial(blocks.VariationalEncoder,
+                      encoder=partial(blocks.Encoder, data_size=n_band, capacity=capacity, latent_size=latent_size,
+                                      ratios=ratios, sample_norm=False, repeat_layers=1, n_out=2))      # v1.gin:44-55
+        gin.bind("ResidualStack", kernel_sizes=[3], dilations_list=[[1, 1], [3, 1], [5, 1]])             # v1.gin:67-69
+        gin.bind("NoiseGenerator", ratios=[4, 4, 4], noise_bands=5)                                       # v1.gin:71-73
+        dec = partial(blocks.Generator, latent_size=latent_size, capacity=capacity, data_size=n_band,
+                      ratios=ratios, loud_stride=1, use_noise=True)                                       # v1.gin:58-65
+        msd = partial(discriminator.MultiScaleDiscriminator, n_discriminators=3,
+                      convnet=partial(discriminator.ConvNet, out_size=1, capacity=capacity, n_layers=4, stride=4,
+                                      conv=nn.Conv1d, kernel_size=15))                                    # v1.gin:75-88
+        stft = partial(core.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128], sample_rate=sampling_rate, magnitude=True)
+        dist = partial(core.AudioDistanceV1, multiscale_stft=stft, log_epsilon=1e-7)
+        return rave.RAVE(latent_size=latent_size, sampling_rate=sampling_rate,
+                         pqmf=partial(pqmf.CachedPQMF, attenuation=100, n_band=n_band), encoder=enc, decoder=dec,
+                         discriminator=msd, phase_1_duration=1000000, gan_loss=core.hinge_gan,
+                         valid_signal_crop=False, feature_matching_fun=partial(core.mean_difference, norm="L1"),
+                         num_skipped_features=0, audio_distance=dist, multiband_audio_distance=dist,
+                         weights={"feature_matching": 10}, update_discriminator_every=2,
+                         n_channels=n_channels, n_bands=n_band)
     if config in ("v2", "v3"):
         capacity = capacity or 96                       # v2.gin:20
         ratios = ratios or [4, 4, 4, 2]                 # v2.gin:19

@@ -38,7 +38,21 @@ def _wrap(fn, key):
 def configurable(fn_or_name=None, **kwargs):
     def deco(fn):
         key = getattr(fn, "__name__", str(fn))
-        out = fn if inspect.isclass(fn) else _wrap(fn, key)
+        if inspect.isclass(fn):
+            # keep the class object (isinstance / inheritance), inject bindings through __init__
+            orig = fn.__init__
+
+            @functools.wraps(orig)
+            def init(self, *args, **kwargs):
+                if type(self) is fn or type(self).__init__ is init:
+                    for k, v in _BINDINGS.get(key, {}).items():
+                        kwargs.setdefault(k, v)
+                return orig(self, *args, **kwargs)
+
+            fn.__init__ = init
+            out = fn
+        else:
+            out = _wrap(fn, key)
         _REGISTRY[key] = out
         return out
 

@@ -154,6 +154,16 @@ class Residual(nn.Module):
             # Snake: alpha needs its own gradient -> unfused activation, fused residual add
             h = c3(a0(x))
             return c1(a2(h), residual=x)
+        if isinstance(unit, nn.Sequential) and len(unit) >= 2 and isinstance(unit[-1], cc.Conv1d) \
+                and unit[-1].groups == 1:
+            # v1 ResidualLayer (rave/blocks.py:48-80): [act, conv]* with the skip added in the last
+            # conv's epilogue
+            mods = list(unit)
+            h = run_fused(nn.Sequential(*mods[:-2]), x) if len(mods) > 2 else x
+            f = _act_of(mods[-2])
+            if f is not None and f[2] is None:
+                return mods[-1](h, act=f[0], slope=f[1], residual=x)
+            return mods[-1](mods[-2](h), residual=x)
         x_net, x_res = self.aligned(x)
         return x_net + x_res
 
@@ -381,3 +391,180 @@ class VariationalEncoder(nn.Module):
         if self.warmed_up:
             z = z.detach()
         return z
+
+
+# --------------------------------------------------------------------------------------------- v1
+class SampleNorm(nn.Module):
+    """rave/blocks.py:25-28."""
+
+    def forward(self, x):
+        return x / torch.norm(x, 2, 1, keepdim=True)
+
+
+class ResidualLayer(nn.Module):
+    """rave/blocks.py:48-80."""
+
+    def __init__(self, dim, kernel_size, dilations, cumulative_delay=0,
+                 activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2)):
+        super().__init__()
+        net = []
+        for d in dilations:
+            net.append(activation(dim))
+            net.append(normalization(cc.Conv1d(dim, dim, kernel_size, dilation=d, bias=False,
+                                               padding=cc.get_padding(kernel_size, dilation=d))))
+        self.net = Residual(cc.CachedSequential(*net), cumulative_delay=cumulative_delay)
+        self.cumulative_delay = self.net.cumulative_delay
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class ResidualBlock(nn.Module):
+    """rave/blocks.py:115-143."""
+
+    def __init__(self, dim, kernel_size, dilations_list, cumulative_delay=0) -> None:
+        super().__init__()
+        layers = [ResidualLayer(dim, kernel_size, dilations) for dilations in dilations_list]
+        self.net = cc.CachedSequential(*layers, cumulative_delay=cumulative_delay)
+        self.cumulative_delay = self.net.cumulative_delay
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class ResidualStack(nn.Module):
+    """rave/blocks.py:146-164 (configs/v1.gin:67-69: kernel_sizes [3], dilations [[1,1],[3,1],[5,1]])."""
+
+    def __init__(self, dim, kernel_sizes=(3,), dilations_list=((1, 1), (3, 1), (5, 1)), cumulative_delay=0) -> None:
+        super().__init__()
+        blocks = [ResidualBlock(dim, k, dilations_list) for k in kernel_sizes]
+        self.net = cc.AlignBranches(*blocks, cumulative_delay=cumulative_delay)
+        self.cumulative_delay = self.net.cumulative_delay
+
+    def forward(self, x):
+        outs = self.net(x)
+        y = outs[0]
+        for o in outs[1:]:
+            y = y + o
+        return y
+
+
+class UpsampleLayer(nn.Module):
+    """rave/blocks.py:167-195."""
+
+    def __init__(self, in_dim, out_dim, ratio, cumulative_delay=0,
+                 activation: Callable[[int], nn.Module] = lambda dim: nn.LeakyReLU(.2)):
+        super().__init__()
+        net = [activation(in_dim)]
+        if ratio > 1:
+            net.append(normalization(cc.ConvTranspose1d(in_dim, out_dim, 2 * ratio, stride=ratio,
+                                                        padding=ratio // 2, bias=False)))
+        else:
+            net.append(normalization(cc.Conv1d(in_dim, out_dim, 3, padding=cc.get_padding(3), bias=False)))
+        self.net = cc.CachedSequential(*net)
+        self.cumulative_delay = 0
+
+    def forward(self, x):
+        return run_fused(self.net, x)
+
+
+class NoiseGenerator(nn.Module):
+    """rave/blocks.py:198-240 (v1; configs/v1.gin:71-73: ratios [4,4,4], noise_bands 5)."""
+
+    def __init__(self, in_size, data_size, ratios=(4, 4, 4), noise_bands=5):
+        super().__init__()
+        net = []
+        channels = [in_size] * len(ratios) + [data_size * noise_bands]
+        for i, r in enumerate(ratios):
+            net.append(cc.Conv1d(channels[i], channels[i + 1], 3, padding=cc.get_padding(3, r), stride=r, bias=False))
+            if i != len(ratios) - 1:
+                net.append(nn.LeakyReLU(.2))
+        self.net = cc.CachedSequential(*net)
+        self.data_size = data_size
+        self.cumulative_delay = 0
+        self.register_buffer("target_size", torch.tensor(int(np.prod(ratios))).long())
+
+    def forward(self, x, noise: Optional[torch.Tensor] = None):
+        amp = mod_sigmoid(run_fused(self.net, x) - 5)
+        amp = amp.permute(0, 2, 1)
+        amp = amp.reshape(amp.shape[0], amp.shape[1], self.data_size, -1)
+        ir = amp_to_impulse_response(amp, self.target_size)
+        if noise is None:
+            noise = torch.rand_like(ir) * 2 - 1
+        out = fft_convolve(noise, ir).permute(0, 2, 1, 3)
+        return out.reshape(out.shape[0], out.shape[1], -1)
+
+
+class Generator(nn.Module):
+    """rave/blocks.py:322-421 (v1 decoder): WN Conv k7 -> [UpsampleLayer, ResidualStack]* -> wave /
+    loudness / noise branches."""
+
+    def __init__(self, latent_size, capacity, data_size, ratios, loud_stride, use_noise, n_channels: int = 1,
+                 recurrent_layer=None):
+        super().__init__()
+        if recurrent_layer is not None:
+            raise NotImplementedError("rave_amd v1 Generator: recurrent_layer (hybrid.gin) is not on the hot path")
+        net = [normalization(cc.Conv1d(latent_size, 2 ** len(ratios) * capacity, 7, padding=cc.get_padding(7), bias=False))]
+        for i, r in enumerate(ratios):
+            in_dim = 2 ** (len(ratios) - i) * capacity
+            out_dim = 2 ** (len(ratios) - i - 1) * capacity
+            net.append(UpsampleLayer(in_dim, out_dim, r))
+            net.append(ResidualStack(out_dim))
+        self.net = cc.CachedSequential(*net)
+        wave_gen = normalization(cc.Conv1d(out_dim, data_size * n_channels, 7, padding=cc.get_padding(7), bias=False))
+        loud_gen = normalization(cc.Conv1d(out_dim, 1, 2 * loud_stride + 1, stride=loud_stride, bias=False,
+                                           padding=cc.get_padding(2 * loud_stride + 1, loud_stride)))
+        branches = [wave_gen, loud_gen]
+        if use_noise:
+            branches.append(NoiseGenerator(out_dim, data_size * n_channels))
+        self.synth = cc.AlignBranches(*branches)
+        self.use_noise = use_noise
+        self.loud_stride = loud_stride
+        self.cumulative_delay = 0
+        self.register_buffer("warmed_up", torch.tensor(0))
+
+    def set_warmed_up(self, state: bool):
+        state = torch.tensor(int(state), device=self.warmed_up.device)
+        self.warmed_up = state
+
+    def forward(self, x, noise: Optional[torch.Tensor] = None):
+        x = self.net(x)
+        br = self.synth.branches
+        waveform, loudness = br[0](x), br[1](x)
+        if self.loud_stride != 1:
+            loudness = loudness.repeat_interleave(self.loud_stride)
+        loudness = loudness.reshape(x.shape[0], 1, -1)
+        waveform = torch.tanh(waveform) * mod_sigmoid(loudness)
+        if self.warmed_up and self.use_noise:
+            waveform = waveform + br[2](x, noise=noise)
+        return waveform
+
+
+class Encoder(nn.Module):
+    """rave/blocks.py:424-503 (v1 encoder): Conv k7, [BatchNorm1d | SampleNorm, LeakyReLU, strided Conv]*,
+    LeakyReLU, grouped Conv k5.  No weight norm; BatchNorm statistics are torch (not a conv)."""
+
+    def __init__(self, data_size, capacity, latent_size, ratios, n_out, sample_norm, repeat_layers,
+                 n_channels: int = 1, recurrent_layer=None, spectrogram=None):
+        super().__init__()
+        if recurrent_layer is not None:
+            raise NotImplementedError("rave_amd v1 Encoder: recurrent_layer is not on the hot path")
+        data_size = data_size or n_channels
+        net = [cc.Conv1d(data_size * n_channels, capacity, 7, padding=cc.get_padding(7), bias=False)]
+        for i, r in enumerate(ratios):
+            in_dim = 2 ** i * capacity
+            out_dim = 2 ** (i + 1) * capacity
+            net.append(SampleNorm() if sample_norm else nn.BatchNorm1d(in_dim))
+            net.append(nn.LeakyReLU(.2))
+            net.append(cc.Conv1d(in_dim, out_dim, 2 * r + 1, padding=cc.get_padding(2 * r + 1, r), stride=r, bias=False))
+            for _ in range(repeat_layers - 1):
+                net.append(SampleNorm() if sample_norm else nn.BatchNorm1d(out_dim))
+                net.append(nn.LeakyReLU(.2))
+                net.append(cc.Conv1d(out_dim, out_dim, 3, padding=cc.get_padding(3), bias=False))
+        net.append(nn.LeakyReLU(.2))
+        net.append(cc.Conv1d(out_dim, latent_size * n_out, 5, padding=cc.get_padding(5), groups=n_out, bias=False))
+        self.net = cc.CachedSequential(*net)
+        self.cumulative_delay = 0
+
+    def forward(self, x):
+        return run_fused(self.net, x)

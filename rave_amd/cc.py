@@ -88,8 +88,6 @@ class Conv1d(nn.Conv1d):
         kwargs.pop("cumulative_delay", 0)
         kwargs["padding"] = 0
         super().__init__(*args, **kwargs)
-        if self.groups != 1:
-            raise NotImplementedError("rave_amd.cc.Conv1d: groups != 1")
         self.cumulative_delay = 0
 
     def script_cache(self):
@@ -101,6 +99,17 @@ class Conv1d(nn.Conv1d):
 
     def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, alpha: Optional[torch.Tensor] = None,
                 residual: Optional[torch.Tensor] = None):
+        if self.groups != 1:
+            # grouped conv (only the v1 Encoder head, rave/blocks.py:490-497, groups = n_out = 2 on a
+            # (B, C, 32) latent): one kernel launch per group on channel slices
+            if alpha is not None or residual is not None:
+                raise NotImplementedError("rave_amd.cc.Conv1d: groups with fused snake/residual")
+            w = _effective_weight(self)
+            xs = x.chunk(self.groups, 1)
+            ws = w.chunk(self.groups, 0)
+            bs = self.bias.chunk(self.groups, 0) if self.bias is not None else [None] * self.groups
+            return torch.cat([ops.conv1d(xi.contiguous(), wi.contiguous(), bi, geom=self.geom(act, slope))
+                              for xi, wi, bi in zip(xs, ws, bs)], 1)
         w, g = _wn_pair(self)
         return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, residual=residual, weight_g=g)
 

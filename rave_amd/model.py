@@ -194,6 +194,31 @@ class RAVE(nn.Module):
 V2_DILATIONS = [[1, 3, 9], [1, 3, 9], [1, 3, 9], [1, 3]]
 
 
+def build_v1(n_channels: int = 1, capacity: int = 64, ratios=(4, 4, 4, 2), latent_size: int = 128,
+             n_band: int = 16, sampling_rate: int = 44100, use_noise: bool = True) -> "RAVE":
+    """configs/v1.gin: v1 Encoder (BatchNorm) / Generator (ResidualStack, loudness + noise branches),
+    multi-scale discriminator only, feature matching L1 x10, discriminator every 2nd step."""
+    cc.set_default_padding_mode("centered")
+    blocks.set_normalization_mode("weight_norm")
+    ratios = list(ratios)
+    enc = partial(blocks.VariationalEncoder,
+                  encoder=partial(blocks.Encoder, data_size=n_band, capacity=capacity, latent_size=latent_size,
+                                  ratios=ratios, n_out=2, sample_norm=False, repeat_layers=1))
+    dec = partial(blocks.Generator, latent_size=latent_size, capacity=capacity, data_size=n_band, ratios=ratios,
+                  loud_stride=1, use_noise=use_noise)
+    msd = partial(discriminator.MultiScaleDiscriminator, n_discriminators=3,
+                  convnet=partial(discriminator.ConvNet, out_size=1, capacity=capacity, n_layers=4, stride=4,
+                                  conv=nn.Conv1d, kernel_size=15))
+    stft = partial(losses.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128], sample_rate=sampling_rate, magnitude=True)
+    dist = partial(losses.AudioDistanceV1, multiscale_stft=stft, log_epsilon=1e-7)
+    return RAVE(latent_size=latent_size, sampling_rate=sampling_rate,
+                pqmf=partial(pqmf.CachedPQMF, attenuation=100, n_band=n_band), encoder=enc, decoder=dec,
+                discriminator=msd, phase_1_duration=1000000, gan_loss=losses.hinge_gan, valid_signal_crop=False,
+                feature_matching_fun=partial(losses.mean_difference, norm="L1"), num_skipped_features=0,
+                audio_distance=dist, multiband_audio_distance=dist, weights={"feature_matching": 10},
+                update_discriminator_every=2, n_channels=n_channels, n_bands=n_band)
+
+
 def build_v2_small(**kw) -> "RAVE":
     """configs/v2_small.gin: CAPACITY 48, RATIOS [4,2,2,2], NoiseGeneratorV2, discriminator every 2nd step."""
     d = dict(capacity=48, ratios=(4, 2, 2, 2), noise=True, update_discriminator_every=2)

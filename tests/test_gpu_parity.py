@@ -568,6 +568,33 @@ def test_v2_small_noise_generator_golden(golden_dir, dev):
         assert rel_l2(named[k].grad, gref) < 2e-4, (k, rel_l2(named[k].grad, gref))
 
 
+def test_v1_generator_side_golden(golden_dir, dev):
+    """configs/v1.gin on the HIP modules: v1 Encoder (BatchNorm1d, strided k=2r+1 convs, grouped head),
+    Generator (UpsampleLayer, ResidualStack of ResidualLayers with fused skip, waveform x loudness,
+    NoiseGenerator when warmed up) vs the reference's golden forward products and 79 gradients."""
+    from rave_amd import model as M
+    g = _load(golden_dir, "v1_tiny.pt")
+    c = g["config"]
+    m = M.build_v1(capacity=c["capacity"], latent_size=c["latent_size"])
+    own = m.state_dict()
+    for k, v in g["state_dict"].items():
+        assert k in own and tuple(own[k].shape) == tuple(v.shape), k
+    m.load_state_dict(g["state_dict"], strict=False)
+    m = m.to(dev).train()
+    zp = m.encode(g["x"].to(dev))
+    assert rel_l2(zp, g["z_params"]) < TOL_E2E
+    z, _ = m.encoder.reparametrize(zp, g["eps"].to(dev))
+    assert rel_l2(m.decoder(z), g["y_cold"]) < TOL_E2E
+    m.decoder.set_warmed_up(True)
+    y = m.decoder(z, noise=g["noise"].to(dev))
+    assert rel_l2(y, g["y_warm"]) < TOL_E2E
+    torch.autograd.backward([y], [g["cot_mb"].to(dev)])
+    named = dict(m.named_parameters())
+    for k, gref in g["grads"].items():
+        assert named[k].grad is not None, k
+        assert rel_l2(named[k].grad, gref) < 2e-4, (k, rel_l2(named[k].grad, gref))
+
+
 def test_v2_full_size_forward_vs_oracle(dev):
     """BASELINE config 2 geometry (v2, CAPACITY 96, 65536 samples), batch 2: PQMF -> EncoderV2 ->
     reparametrize -> GeneratorV2 -> PQMF^-1 on the GPU vs the CPU oracle; <= 1e-4 relative L2."""
