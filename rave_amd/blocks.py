@@ -393,6 +393,98 @@ class VariationalEncoder(nn.Module):
         return z
 
 
+class WasserteinEncoder(nn.Module):
+    """rave/blocks.py:748-791 (configs/wasserstein.gin): MMD regulariser on the latent -- elementwise /
+    small-matrix torch ops around the HIP encoder; ``eps`` arguments inject the random draws."""
+
+    def __init__(self, encoder_cls, noise_augmentation: int = 0, n_channels: int = 1):
+        super().__init__()
+        self.encoder = encoder_cls(n_channels=n_channels)
+        self.register_buffer("warmed_up", torch.tensor(0))
+        self.noise_augmentation = noise_augmentation
+
+    def compute_mean_kernel(self, x, y):
+        kernel_input = (x[:, None] - y[None]).pow(2).mean(2) / x.shape[-1]
+        return torch.exp(-kernel_input).mean()
+
+    def compute_mmd(self, x, y):
+        return self.compute_mean_kernel(x, x) + self.compute_mean_kernel(y, y) - 2 * self.compute_mean_kernel(x, y)
+
+    def reparametrize(self, z, eps: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        z_reshaped = z.permute(0, 2, 1).reshape(-1, z.shape[1])
+        reg = self.compute_mmd(z_reshaped, torch.randn_like(z_reshaped) if eps is None else eps)
+        if self.noise_augmentation:
+            if noise is None:
+                noise = torch.randn(z.shape[0], self.noise_augmentation, z.shape[-1]).type_as(z)
+            z = torch.cat([z, noise], 1)
+        return z, reg.mean()
+
+    def set_warmed_up(self, state: bool):
+        state = torch.tensor(int(state), device=self.warmed_up.device)
+        self.warmed_up = state
+
+    def forward(self, x: torch.Tensor):
+        z = self.encoder(x)
+        if self.warmed_up:
+            z = z.detach()
+        return z
+
+
+class SphericalEncoder(nn.Module):
+    """rave/blocks.py:833-849 (configs/spherical.gin)."""
+
+    def __init__(self, encoder_cls, n_channels: int = 1) -> None:
+        super().__init__()
+        self.encoder = encoder_cls(n_channels=n_channels)
+
+    def reparametrize(self, z, eps=None):
+        norm_z = z / torch.norm(z, p=2, dim=1, keepdim=True)
+        return norm_z, torch.zeros_like(z).mean()
+
+    def set_warmed_up(self, state: bool):
+        pass
+
+    def forward(self, x: torch.Tensor):
+        return self.encoder(x)
+
+
+class DiscreteEncoder(nn.Module):
+    """rave/blocks.py:794-830 (configs/discrete.gin) with the quantiser DISABLED, which is the state
+    the shipped trainer always leaves it in (QuantizeCallback.on_train_batch_ is never called by
+    Lightning -- SURVEY.md Appendix B #10): pass-through + ``noise_augmentation`` extra noise channels.
+    The residual vector quantiser itself (rave/quantization.py) is out of the hot-path scope."""
+
+    def __init__(self, encoder_cls, vq_cls=None, num_quantizers: int = 16, noise_augmentation: int = 0,
+                 n_channels: int = 1):
+        super().__init__()
+        self.encoder = encoder_cls(n_channels=n_channels)
+        self.rvq = vq_cls() if vq_cls is not None else None
+        self.num_quantizers = num_quantizers
+        self.register_buffer("warmed_up", torch.tensor(0))
+        self.register_buffer("enabled", torch.tensor(0))
+        self.noise_augmentation = noise_augmentation
+
+    def reparametrize(self, z, eps=None, noise: Optional[torch.Tensor] = None):
+        if self.enabled:
+            if self.rvq is None:
+                raise NotImplementedError("rave_amd DiscreteEncoder: RVQ (rave/quantization.py) is out of scope")
+            z, diff, _ = self.rvq(z)
+        else:
+            diff = torch.zeros_like(z).mean()
+        if self.noise_augmentation:
+            if noise is None:
+                noise = torch.randn(z.shape[0], self.noise_augmentation, z.shape[-1]).type_as(z)
+            z = torch.cat([z, noise], 1)
+        return z, diff
+
+    def set_warmed_up(self, state: bool):
+        state = torch.tensor(int(state), device=self.warmed_up.device)
+        self.warmed_up = state
+
+    def forward(self, x):
+        return self.encoder(x)
+
+
 # --------------------------------------------------------------------------------------------- v1
 class SampleNorm(nn.Module):
     """rave/blocks.py:25-28."""

@@ -99,3 +99,38 @@ def test_streaming_mode_is_refused():
     cc.use_cached_conv(False)
     with pytest.raises(NotImplementedError):
         cc.use_cached_conv(True)
+
+
+def _have_reference():
+    import ref_import
+    return ref_import.reference_available()
+
+
+@pytest.mark.skipif(not _have_reference(), reason="/root/reference not present (GPU box)")
+def test_latent_wrappers_match_reference():
+    """WasserteinEncoder / SphericalEncoder / DiscreteEncoder(disabled) reparametrize == reference
+    (rave/blocks.py:748-849); pure latent-space torch maths, no HIP call."""
+    from ref_import import import_reference
+    import_reference()
+    from rave import blocks as rb
+    from rave_amd import blocks as hb
+    enc = lambda n_channels=1: torch.nn.Identity()
+    z = torch.randn(3, 8, 16)
+    eps = torch.randn(3 * 16, 8)
+    noise = torch.randn(3, 4, 16)
+    w_ref, w_hip = rb.WasserteinEncoder(enc, noise_augmentation=0), hb.WasserteinEncoder(enc, noise_augmentation=0)
+    torch.manual_seed(1)
+    zr, rr = w_ref.reparametrize(z)
+    torch.manual_seed(1)
+    zh, rh = w_hip.reparametrize(z)
+    assert torch.equal(zr, zh) and torch.allclose(rr, rh)
+    s_ref, s_hip = rb.SphericalEncoder(enc), hb.SphericalEncoder(enc)
+    assert torch.equal(s_ref.reparametrize(z)[0], s_hip.reparametrize(z)[0])
+    d_ref = rb.DiscreteEncoder(enc, vq_cls=lambda: torch.nn.Identity(), num_quantizers=16, noise_augmentation=4)
+    d_hip = hb.DiscreteEncoder(enc, vq_cls=None, num_quantizers=16, noise_augmentation=4)
+    torch.manual_seed(2)
+    a, da = d_ref.reparametrize(z)
+    torch.manual_seed(2)
+    b, db = d_hip.reparametrize(z)
+    assert torch.equal(a, b) and float(da) == float(db) == 0.0
+    assert set(d_ref.state_dict()) == set(d_hip.state_dict())
