@@ -377,7 +377,9 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         const int per_ch = maxtaps * BM + p.nb * p.pitch;
         // floats per pipeline stage (2 stages per workgroup): 20 KiB stages give 4 workgroups per CU and
         // measured best when they still hold >= 8 channels per chunk; otherwise 40 KiB stages (2 per CU)
-        int budget = budget_env > 0 ? budget_env : 5 * 1024;
+        // measured per layer (profiles/round1_layer_table_b32.txt sweep): 20 KiB stages (4 workgroups/CU)
+        // for the small-channel / long-sequence layers, 24 KiB (3/CU) from 256 channels up
+        int budget = budget_env > 0 ? budget_env : (p.C >= 256 ? 6 * 1024 : 5 * 1024);
         ck = ((budget - 512) / per_ch) & ~1;
         if (budget_env <= 0 && ck < 8) {
             budget = 10 * 1024;

@@ -299,6 +299,39 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_dma_kernel(const WgradP p) 
             const float* rl = r_lds + w;
             const float* sl = s_lds + w;
             int rr = 0;
+            if (p.vec) {
+                // 16-byte aligned rows (pitch = 4 mod 32 floats): one conflict-free ds_read_b128 per row
+                // tile delivers the A operand of FOUR k-steps.  K pairing inside a group of 8 positions:
+                // step u multiplies positions (rr+u) [lanes 0-31] and (rr+4+u) [lanes 32-63], so every
+                // lane consumes its whole float4 and no component select is needed (A and B agree).
+                for (; rr + 8 <= p.rk; rr += 8) {
+                    f32x4 a4[TM];
+                    float bb[4][TN];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        a4[tm] = *reinterpret_cast<const f32x4*>(rl + ar[tm] - kh + rr + 4 * kh);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) bb[u][tn] = sl[sb[tn] - kh * is + (rr + 4 * kh + u) * is];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            if (SLEAKY) bb[u][tn] = bb[u][tn] > 0.f ? bb[u][tn] : bb[u][tn] * p.s_slope;
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            float av = a4[tm][u];
+                            if (RLEAKY) av = av > 0.f ? av : av * p.r_slope;
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bb[u][tn], acc[tm][tn], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             for (; rr + 8 <= p.rk; rr += 8) {
                 // all 4 x (TM + TN) LDS reads of the group are issued back to back (sched_barrier keeps
                 // hipcc from re-serialising them into read -> wait -> MFMA), then the 4 x TM x TN MFMAs
