@@ -330,9 +330,11 @@ Plan plan_split(const ConvP& p, int BM, int col_tiles) {
     Plan pl{};
     pl.blocks = col_tiles * rh_cdiv(p.M, BM) * p.nphase;
     pl.total_chunks = rh_cdiv(p.C, p.ck);
+    static const int split_below = [] { const char* e = getenv("RH_CONV_SPLIT_BELOW"); return e ? atoi(e) : 512; }();
+    static const int split_target = [] { const char* e = getenv("RH_CONV_SPLIT_TARGET"); return e ? atoi(e) : 768; }();
     int z = 1;
-    if (pl.blocks < 512) {
-        z = rh_cdiv(768, pl.blocks);
+    if (pl.blocks < split_below) {
+        z = rh_cdiv(split_target, pl.blocks);
         const int zmax = pl.total_chunks / 2;
         if (z > zmax) z = zmax;
         if (z > 16) z = 16;
@@ -379,9 +381,9 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         // measured best when they still hold >= 8 channels per chunk; otherwise 40 KiB stages (2 per CU)
         // measured per layer (profiles/round1_layer_table_b32.txt sweep): 20 KiB stages (4 workgroups/CU)
         // for the small-channel / long-sequence layers, 24 KiB (3/CU) from 256 channels up
-        int budget = budget_env > 0 ? budget_env : (p.C >= 256 ? 6 * 1024 : 5 * 1024);
+        int budget = budget_env > 0 ? budget_env : (p.C >= 192 ? 6 * 1024 : 5 * 1024);
         ck = ((budget - 512) / per_ch) & ~1;
-        if (budget_env <= 0 && ck < 8) {
+        if (budget_env <= 0 && ck < (p.C >= 192 ? 4 : 8)) {
             budget = 10 * 1024;
             ck = ((budget - 512) / per_ch) & ~1;
         }
