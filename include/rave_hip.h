@@ -107,6 +107,16 @@ int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd, f
 int rh_conv1d_pack_wn_f32(const rh_conv1d_desc* d, const float* v, const float* g, float* norms,
                           float* scale, float* wp_fwd, float* wp_bwd, rh_stream_t stream);
 
+/* Batched form of rh_conv1d_pack_wn_f32 for a whole model: the caller fills one opaque item per
+ * weight-normalised conv (host memory, rh_prep_item_bytes() each, pointers are DEVICE pointers to the
+ * parameters and to persistent norms / scale / packed buffers), links them, copies the array to the
+ * device once, and then refreshes every layer's packed weights with TWO launches per training step. */
+int64_t rh_prep_item_bytes(void);
+int rh_prep_fill_item(const rh_conv1d_desc* d, const float* v, const float* g, float* norms, float* scale,
+                      float* wp_fwd, float* wp_bwd, void* item_host);
+int rh_prep_link(void* items_host, int32_t n, int64_t* total_rows, int64_t* total_blocks);
+int rh_prep_run_f32(const void* items_dev, int32_t n, int64_t total_rows, int64_t total_blocks, rh_stream_t stream);
+
 /* ---- convolution ---------------------------------------------------------------------- */
 
 /* y = conv(act(x)) + bias + residual.   bias (c_out), residual (B,c_out,l_out*inner) and

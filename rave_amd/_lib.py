@@ -43,6 +43,10 @@ def _load() -> C.CDLL:
         "rh_conv1d_packed_floats": ([D, C.c_int], I64),
         "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
         "rh_conv1d_pack_wn_f32": ([D, P, P, P, P, P, P, P], C.c_int),
+        "rh_prep_item_bytes": ([], I64),
+        "rh_prep_fill_item": ([D, P, P, P, P, P, P, P], C.c_int),
+        "rh_prep_link": ([P, I32, C.POINTER(I64), C.POINTER(I64)], C.c_int),
+        "rh_prep_run_f32": ([P, I32, I64, I64, P], C.c_int),
         "rh_conv1d_fwd_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_conv1d_bwd_data_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_conv1d_fwd_workspace_bytes": ([D], I64),

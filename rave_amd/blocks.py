@@ -150,7 +150,8 @@ class Residual(nn.Module):
             if f0 is not None and f2 is not None and f0[2] is None and f2[2] is None:
                 w3, g3 = cc._wn_pair(c3)
                 w1, g1 = cc._wn_pair(c1)
-                return ops.residual_unit(x, w3, w1, c3.geom(f0[0], f0[1]), c1.geom(f2[0], f2[1]), w3_g=g3, w1_g=g1)
+                return ops.residual_unit(x, w3, w1, c3.geom(f0[0], f0[1]), c1.geom(f2[0], f2[1]), w3_g=g3, w1_g=g1,
+                                         pre3=getattr(c3, "_prepacked", None), pre1=getattr(c1, "_prepacked", None))
             # Snake: alpha needs its own gradient -> unfused activation, fused residual add
             h = c3(a0(x))
             return c1(a2(h), residual=x)

@@ -111,7 +111,8 @@ class Conv1d(nn.Conv1d):
             return torch.cat([ops.conv1d(xi.contiguous(), wi.contiguous(), bi, geom=self.geom(act, slope))
                               for xi, wi, bi in zip(xs, ws, bs)], 1)
         w, g = _wn_pair(self)
-        return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, residual=residual, weight_g=g)
+        return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, residual=residual, weight_g=g,
+                          prepacked=getattr(self, "_prepacked", None))
 
 
 class ConvTranspose1d(nn.ConvTranspose1d):
@@ -133,7 +134,8 @@ class ConvTranspose1d(nn.ConvTranspose1d):
 
     def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, alpha: Optional[torch.Tensor] = None):
         w, g = _wn_pair(self)
-        return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, weight_g=g)
+        return ops.conv1d(x, w, self.bias, geom=self.geom(act, slope), alpha=alpha, weight_g=g,
+                          prepacked=getattr(self, "_prepacked", None))
 
 
 class PlainConv1d(nn.Conv1d):
@@ -149,7 +151,7 @@ class PlainConv1d(nn.Conv1d):
         g = ConvGeom(stride=self.stride[0], dilation=self.dilation[0], pad_left=self.padding[0],
                      pad_right=self.padding[0], act=act, slope=slope)
         w, wg = _wn_pair(self)
-        return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg)
+        return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg, prepacked=getattr(self, "_prepacked", None))
 
 
 class Conv2dK1(nn.Conv2d):
@@ -171,7 +173,7 @@ class Conv2dK1(nn.Conv2d):
         g = ConvGeom(stride=self.stride[0], dilation=1, pad_left=self.padding[0], pad_right=self.padding[0],
                      act=act, slope=slope, inner=inner, fold=period is not None)
         w, wg = _wn_pair(self)
-        return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg)
+        return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg, prepacked=getattr(self, "_prepacked", None))
 
 
 class CachedSequential(nn.Sequential):

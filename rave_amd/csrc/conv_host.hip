@@ -255,6 +255,107 @@ extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float
 int rh_weight_norm_scales(const float* v, const float* g, int64_t rows, int64_t cols, float* norms, float* scale,
                           hipStream_t stream);
 
+// ---- batched weight preparation: every weight-normalised conv of a model in TWO launches ------------
+// (per-layer launches of weight_norm_scales + pack cost ~1.2 ms of a 21 ms v2 step: ~110 tiny kernels)
+struct PrepItem {
+    const float* v;
+    const float* g;
+    float* norms;
+    float* scale;
+    PackP fwd, bwd;          // .w = v, .scale = scale, .wp = persistent packed buffers
+    long rows, cols;
+    long row_begin;          // prefix over items (rows)
+    long blk_begin;          // prefix over items (256-element pack blocks)
+};
+
+namespace {
+
+__device__ __forceinline__ int find_item(const PrepItem* items, int n, long key, bool rows) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const long b = rows ? items[mid].row_begin : items[mid].blk_begin;
+        if (b <= key) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __restrict__ items, int n) {
+    __shared__ float red[4];
+    const int it = find_item(items, n, blockIdx.x, true);
+    const PrepItem& p = items[it];
+    const long r = (long)blockIdx.x - p.row_begin;
+    const float* vr = p.v + r * p.cols;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < p.cols; e += 256) { const float a = vr[e]; s += a * a; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+        p.norms[r] = norm;
+        p.scale[r] = p.g[r] / norm;
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_pack_kernel(const PrepItem* __restrict__ items, int n) {
+    const int it = find_item(items, n, blockIdx.x, false);
+    const PrepItem& p = items[it];
+    const long e = ((long)blockIdx.x - p.blk_begin) * 256 + threadIdx.x;
+    if (e < p.fwd.total) pack_one_elem(p.fwd, e);
+    else if (e - p.fwd.total < p.bwd.total) pack_one_elem(p.bwd, e - p.fwd.total);
+}
+
+}  // namespace
+
+extern "C" int64_t rh_prep_item_bytes(void) { return (int64_t)sizeof(PrepItem); }
+
+extern "C" int rh_prep_fill_item(const rh_conv1d_desc* d, const float* v, const float* g, float* norms, float* scale,
+                                 float* wp_fwd, float* wp_bwd, void* item) {
+    if (int e = validate(d)) return e;
+    RH_REQUIRE(v && g && norms && scale && wp_fwd && item, RH_ERR_INVALID, "prep_fill_item: null pointer");
+    PrepItem* p = (PrepItem*)item;
+    *p = PrepItem{};
+    p->v = v; p->g = g; p->norms = norms; p->scale = scale;
+    p->rows = d->transposed ? d->c_in : d->c_out;
+    p->cols = (long)(d->transposed ? d->c_out : d->c_in) * d->kernel;
+    if (int e = fill_pack(d, 0, v, scale, wp_fwd, &p->fwd)) return e;
+    if (int e = fill_pack(d, 1, v, scale, wp_bwd, &p->bwd)) return e;
+    return RH_OK;
+}
+
+extern "C" int rh_prep_link(void* items, int32_t n, int64_t* total_rows, int64_t* total_blocks) {
+    RH_REQUIRE(items && total_rows && total_blocks && n >= 0, RH_ERR_INVALID, "prep_link: bad arguments");
+    PrepItem* p = (PrepItem*)items;
+    long rows = 0, blks = 0;
+    for (int i = 0; i < n; ++i) {
+        p[i].row_begin = rows;
+        p[i].blk_begin = blks;
+        rows += p[i].rows;
+        blks += (p[i].fwd.total + p[i].bwd.total + 255) / 256;
+    }
+    *total_rows = rows;
+    *total_blocks = blks;
+    return RH_OK;
+}
+
+extern "C" int rh_prep_run_f32(const void* items_dev, int32_t n, int64_t total_rows, int64_t total_blocks,
+                               rh_stream_t stream) {
+    RH_REQUIRE(items_dev && n > 0, RH_ERR_INVALID, "prep_run: bad arguments");
+    if (total_rows > 0) {
+        hipLaunchKernelGGL(prep_scales_kernel, dim3((unsigned)total_rows), dim3(256), 0, (hipStream_t)stream,
+                           (const PrepItem*)items_dev, n);
+        if (int e = rh_check_launch("prep_scales")) return e;
+    }
+    if (total_blocks > 0) {
+        hipLaunchKernelGGL(prep_pack_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const PrepItem*)items_dev, n);
+        return rh_check_launch("prep_pack");
+    }
+    return RH_OK;
+}
+
 extern "C" int rh_conv1d_pack_wn_f32(const rh_conv1d_desc* d, const float* v, const float* g, float* norms,
                                      float* scale, float* wp_fwd, float* wp_bwd, rh_stream_t stream) {
     if (int e = validate(d)) return e;

@@ -69,6 +69,7 @@ class RAVE(nn.Module):
         self.register_buffer("receptive_field", torch.tensor([0, 0]).long())
         self.logged: Dict[str, torch.Tensor] = {}
         self._opts = None
+        self._prep = None
 
     # ---- rave/model.py:226-236
     def configure_optimizers(self):
@@ -116,6 +117,15 @@ class RAVE(nn.Module):
         """``eps`` injects the reparametrisation noise (parity runs); ``grad_sync(optimizer_index)``
         is called between backward and optimizer.step (data-parallel gradient averaging)."""
         gen_opt, dis_opt = self.optimizers()
+        # all weight-normalised convs: weight norm + MFMA repack refreshed in two launches (plumbing;
+        # the reference's weight_norm pre-hooks do the same work layer by layer)
+        if batch.is_cuda:
+            from .prep import WeightPrep
+            if self._prep is None:
+                self._prep = (WeightPrep(nn.ModuleList([self.encoder, self.decoder])), WeightPrep(self.discriminator))
+            self._prep[0].run()
+            if self.warmed_up:       # the discriminator only runs (and only then normalises its weights) in phase 2
+                self._prep[1].run()
         x_raw = batch
         x_raw.requires_grad = True
         batch_size = x_raw.shape[:-2]
@@ -186,6 +196,9 @@ class RAVE(nn.Module):
                 grad_sync(0)
             gen_opt.step()
 
+        if self._prep is not None:
+            self._prep[0].release()
+            self._prep[1].release()
         self.logged = dict(loss_gen)
         self.logged["loss_dis"] = loss_dis
         return self.logged

@@ -141,9 +141,13 @@ def _shapes(x: Tensor, weight: Tensor, g: ConvGeom):
     return b, c_in, c_out, l_in, l_out, k, in_valid, out_shape
 
 
-def _pack(d, w3, g, need_bwd, dev, s):
+def _pack(d, w3, g, need_bwd, dev, s, prepacked=None):
     """Packed weight copies for one conv; with ``g`` the weight norm g*v/||v|| is folded into the
-    repack (rh_conv1d_pack_wn_f32).  Returns (wp_fwd, wp_bwd, norms)."""
+    repack (rh_conv1d_pack_wn_f32).  Returns (wp_fwd, wp_bwd, norms).  ``prepacked`` = the same
+    triple already produced for the current weights by rave_amd.prep.WeightPrep (two launches for
+    the whole model instead of two per layer)."""
+    if prepacked is not None:
+        return prepacked
     dref = C.byref(d)
     wp_f = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 0), device=dev, dtype=torch.float32)
     wp_b = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 1), device=dev, dtype=torch.float32) if need_bwd else None
@@ -174,14 +178,14 @@ class _ConvFn(torch.autograd.Function):
     folded in).  rh_conv1d_fwd_f32 and its gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, g, bias, alpha, residual, geom: ConvGeom):
+    def forward(ctx, x, weight, g, bias, alpha, residual, geom: ConvGeom, prepacked=None):
         x = _chk(x, "x"); weight = _chk(weight, "weight"); g = _chk(g, "weight_g"); bias = _chk(bias, "bias")
         alpha = _chk(alpha, "alpha"); residual = _chk(residual, "residual")
         w3 = weight.reshape(weight.shape[0], weight.shape[1], -1) if weight.dim() == 4 else weight
         b, c_in, c_out, l_in, l_out, k, in_valid, out_shape = _shapes(x, w3, geom)
         d = _desc(geom, b, c_in, c_out, l_in, l_out, k, in_valid)
         s = L.stream()
-        wp_f, wp_b, norms = _pack(d, w3, g, ctx.needs_input_grad[0], x.device, s)
+        wp_f, wp_b, norms = _pack(d, w3, g, ctx.needs_input_grad[0], x.device, s, prepacked)
         y = torch.empty(out_shape, device=x.device, dtype=torch.float32)
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError(f"rave_amd conv: residual shape {tuple(residual.shape)} != output {tuple(y.shape)}")
@@ -220,14 +224,14 @@ class _ConvFn(torch.autograd.Function):
             raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.blocks.Snake + conv")
         if ctx.has_res and ctx.needs_input_grad[5]:
             dres = dy
-        return dx, dw, dg, db, None, dres, None
+        return dx, dw, dg, db, None, dres, None, None
 
 
 def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, geom: ConvGeom,
            alpha: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-           weight_g: Optional[Tensor] = None) -> Tensor:
+           weight_g: Optional[Tensor] = None, prepacked=None) -> Tensor:
     """``weight_g`` given: ``weight`` is the weight-norm direction v and w = g*v/||v|| (dim 0)."""
-    return _ConvFn.apply(x, weight, weight_g, bias, alpha, residual, geom)
+    return _ConvFn.apply(x, weight, weight_g, bias, alpha, residual, geom, prepacked)
 
 
 class _WeightNormFn(torch.autograd.Function):
@@ -269,7 +273,7 @@ class _ResidualUnitFn(torch.autograd.Function):
     activations, padding, weight norm and the residual add live inside the kernels."""
 
     @staticmethod
-    def forward(ctx, x, w3, g3w, w1, g1w, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom):
+    def forward(ctx, x, w3, g3w, w1, g1w, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom, pre3=None, pre1=None):
         x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1"); g3w = _chk(g3w, "g3"); g1w = _chk(g1w, "g1")
         alpha0 = _chk(alpha0, "alpha0"); alpha2 = _chk(alpha2, "alpha2")
         b, c, l = x.shape
@@ -277,8 +281,8 @@ class _ResidualUnitFn(torch.autograd.Function):
         d3 = _desc(g3, b, c, c, l, l, k)
         d1 = _desc(g1, b, c, c, l, l, 1)
         s = L.stream()
-        wp3f, wp3b, n3 = _pack(d3, w3, g3w, True, x.device, s)
-        wp1f, wp1b, n1 = _pack(d1, w1, g1w, True, x.device, s)
+        wp3f, wp3b, n3 = _pack(d3, w3, g3w, True, x.device, s, pre3)
+        wp1f, wp1b, n1 = _pack(d1, w1, g1w, True, x.device, s, pre1)
         h = torch.empty_like(x)
         y = torch.empty_like(x)
         L.check(_fwd(d3, x, wp3f, None, alpha0, None, h, s), "unit k3")
@@ -321,12 +325,13 @@ class _ResidualUnitFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             # dx = act'(x) * dgrad_k3(dh) + dy   (residual gradient fused as `add`)
             L.check(_dgrad(d3, dh, wp3b, x, alpha0, dy, dx, s), "unit k3 dgrad")
-        return dx, dw3, dg3, dw1, dg1, None, None, None, None
+        return dx, dw3, dg3, dw1, dg1, None, None, None, None, None, None
 
 
-def residual_unit(x, w3, w1, g3: ConvGeom, g1: ConvGeom, alpha0=None, alpha2=None, w3_g=None, w1_g=None) -> Tensor:
+def residual_unit(x, w3, w1, g3: ConvGeom, g1: ConvGeom, alpha0=None, alpha2=None, w3_g=None, w1_g=None,
+                  pre3=None, pre1=None) -> Tensor:
     """``w3_g`` / ``w1_g`` given: w3 / w1 are weight-norm directions (v) and the gains are folded in."""
-    return _ResidualUnitFn.apply(x, w3, w3_g, w1, w1_g, alpha0, alpha2, g3, g1)
+    return _ResidualUnitFn.apply(x, w3, w3_g, w1, w1_g, alpha0, alpha2, g3, g1, pre3, pre1)
 
 
 # --------------------------------------------------------------------------- PQMF

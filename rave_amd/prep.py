@@ -1,0 +1,85 @@
+"""Batched weight preparation: the weight norm g*v/||v|| and both MFMA-friendly packed copies of every
+weight-normalised conv of a model in TWO kernel launches per training step (rh_prep_run_f32), instead
+of two launches per layer.  The reference recomputes every normalised weight once per forward
+(torch.nn.utils.weight_norm pre-hook, rave/blocks.py:15-22); this does the same work, batched.
+
+Usage (rave_amd/model.py does this inside training_step)::
+
+    prep = WeightPrep(model)      # once, after .to(device)
+    prep.run()                    # start of every step: refresh all packed weights
+    ... forward / backward ...    # conv modules pick up module._prepacked
+    prep.release()                # end of step: later stray forwards re-pack on their own
+
+Packed buffers are persistent (allocated once); a step's backward reads them before the next
+``run()`` overwrites them (same stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import cc
+from .ops import ConvGeom, _desc
+
+
+def _geom_of(m: nn.Module) -> ConvGeom:
+    if isinstance(m, (cc.Conv1d, cc.ConvTranspose1d)):
+        return m.geom()
+    if isinstance(m, cc.PlainConv1d):
+        return ConvGeom(stride=m.stride[0], dilation=m.dilation[0], pad_left=m.padding[0], pad_right=m.padding[0])
+    if isinstance(m, cc.Conv2dK1):
+        return ConvGeom(stride=m.stride[0], pad_left=m.padding[0], pad_right=m.padding[0])
+    raise TypeError(type(m))
+
+
+class WeightPrep:
+    def __init__(self, model: nn.Module):
+        self.mods: List[nn.Module] = [m for m in model.modules()
+                                      if isinstance(m, (cc.Conv1d, cc.ConvTranspose1d, cc.PlainConv1d, cc.Conv2dK1))
+                                      and getattr(m, "weight_g", None) is not None and m.groups == 1
+                                      and m.weight_v.is_cuda]
+        self.n = len(self.mods)
+        self.bufs = []
+        if self.n == 0:
+            return
+        isz = L.lib.rh_prep_item_bytes()
+        host = (C.c_uint8 * (isz * self.n))()
+        dev = self.mods[0].weight_v.device
+        for i, m in enumerate(self.mods):
+            v, g = m.weight_v, m.weight_g
+            k = v.shape[2]
+            transposed = isinstance(m, cc.ConvTranspose1d)
+            c_in, c_out = (v.shape[0], v.shape[1]) if transposed else (v.shape[1], v.shape[0])
+            d = _desc(_geom_of(m), 1, c_in, c_out, 1, 1, k)
+            dref = C.byref(d)
+            rows = v.shape[0]
+            ns = torch.empty(2, rows, device=dev, dtype=torch.float32)
+            wp_f = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 0), device=dev, dtype=torch.float32)
+            wp_b = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 1), device=dev, dtype=torch.float32)
+            item = C.cast(C.byref(host, i * isz), C.c_void_p)
+            L.check(L.lib.rh_prep_fill_item(dref, L.ptr(v), L.ptr(g), L.ptr(ns[0]), L.ptr(ns[1]), L.ptr(wp_f),
+                                            L.ptr(wp_b), item), "prep_fill_item")
+            self.bufs.append((wp_f, wp_b, ns[0], ns, v.data_ptr(), g.data_ptr()))
+        tr, tb = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib.rh_prep_link(C.cast(host, C.c_void_p), self.n, C.byref(tr), C.byref(tb)), "prep_link")
+        self.total_rows, self.total_blocks = tr.value, tb.value
+        self.items = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+
+    def run(self) -> None:
+        if self.n == 0:
+            return
+        for m, b in zip(self.mods, self.bufs):
+            if m.weight_v.data_ptr() != b[4] or m.weight_g.data_ptr() != b[5]:
+                raise RuntimeError("rave_amd.WeightPrep: a parameter was re-allocated; rebuild the WeightPrep")
+        L.check(L.lib.rh_prep_run_f32(self.items.data_ptr(), self.n, self.total_rows, self.total_blocks, L.stream()),
+                "prep_run")
+        for m, b in zip(self.mods, self.bufs):
+            m._prepacked = (b[0], b[1], b[2])
+
+    def release(self) -> None:
+        for m in self.mods:
+            m._prepacked = None
