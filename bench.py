@@ -212,15 +212,20 @@ def main():
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
                                       "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}
         # ---- forward-only leg of the north-star target (PQMF + conv stacks, no_grad)
+        def fwd_once():
+            m.prepare_weights()          # weight norm + repack of all layers (part of every forward)
+            m.decode(m.encoder.reparametrize(m.encode(x))[0])
+            m.release_weights()
+
         with torch.no_grad():
             for _ in range(2):
-                m.decode(m.encoder.reparametrize(m.encode(x))[0])
+                fwd_once()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             nf = 5
             for _ in range(nf):
-                m.decode(m.encoder.reparametrize(m.encode(x))[0])
+                fwd_once()
             e1.record()
             torch.cuda.synchronize()
             t_fwd = e0.elapsed_time(e1) * 1e-3 / nf

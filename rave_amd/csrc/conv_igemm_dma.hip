@@ -18,6 +18,11 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+#ifndef RH_READS_FIRST
+#define RH_READS_FIRST 1
+#endif
+constexpr bool READS_FIRST = RH_READS_FIRST != 0;
+
 __device__ __forceinline__ int ibase_of(int n, int inner, int is) {
     if (inner == 1) return n * is;
     const int r = n / inner;
@@ -32,7 +37,7 @@ __device__ __forceinline__ unsigned mdiv(unsigned n, unsigned magic) { return (n
 
 constexpr unsigned kOOB = 0x80000000u;  // >= any descriptor size we accept -> DMA writes zeros
 
-template <int TM, int TN, int WM, int WN, bool LEAKY, bool VEC>
+template <int TM, int TN, int WM, int WN, bool LEAKY, bool VEC, bool CTAIL>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP p) {
     constexpr int BM = TM * WM * 32;
     constexpr int NW = WM * WN;
@@ -98,7 +103,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
     // next to the sequence (or 0 outside the tensor) and the B operand is masked at read time with
     // a per-lane bitmask over the taps -- padded positions never reach the matrix cores.
     constexpr int kNX = 8, kNWS = 10;
-    unsigned xo[VEC ? kNX : 1], xc[VEC ? kNX : 1], wo[VEC ? kNWS : 1], wc[VEC ? kNWS : 1];
+    // CTAIL: the last K chunk is partial (C % ck != 0) -> every slot also remembers its channel so that
+    // it can be switched off; otherwise those registers are not even allocated
+    unsigned xo[VEC ? kNX : 1], xc[VEC && CTAIL ? kNX : 1], wo[VEC ? kNWS : 1], wc[VEC && CTAIL ? kNWS : 1];
     unsigned long long vm[TN];
     bool bnd = false;
     int nx = 0, nws = 0, x_floats = 0;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
             const unsigned c = row - bl * p.ck;
             const bool ok = row < (unsigned)xrows && b0 + bl < (unsigned)p.B;
             xo[i] = ok ? (bl * p.C + c) * (unsigned)p.in_row + 4u * v : kOOB;
-            xc[i] = c;
+            if (CTAIL) xc[i] = c;
         }
 #pragma unroll
         for (int i = 0; i < kNWS; ++i) {
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
             const unsigned c = kr - t * p.ck;
             const bool ok = kr < (unsigned)wrows && m0 + col < (unsigned)p.Mp;
             wo[i] = ok ? (t * p.C + c) * p.Mp + m0 + col : kOOB;
-            wc[i] = c;
+            if (CTAIL) wc[i] = c;
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
 #pragma unroll
             for (int i = 0; i < kNWS; ++i) {
                 if (i < nws && (wave + NW * i) < w_instrs) {
-                    const unsigned off = (wo[i] == kOOB || c0 + wc[i] >= (unsigned)p.C) ? kOOB : (wbase + wo[i]) * 4u;
+                    bool dead = wo[i] == kOOB;
+                    if (CTAIL) dead = dead || c0 + wc[i] >= (unsigned)p.C;
+                    const unsigned off = dead ? kOOB : (wbase + wo[i]) * 4u;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(stage + (wave + NW * i) * 256), 16, off, 0, 0, 0);
                 }
             }
@@ -159,7 +168,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
 #pragma unroll
             for (int i = 0; i < kNX; ++i) {
                 if (i < nx && (wave + NW * i) * 256 < x_floats) {
-                    const unsigned off = (xo[i] == kOOB || c0 + xc[i] >= (unsigned)p.C) ? kOOB : (xbase + xo[i]) * 4u;
+                    bool dead = xo[i] == kOOB;
+                    if (CTAIL) dead = dead || c0 + xc[i] >= (unsigned)p.C;
+                    const unsigned off = dead ? kOOB : (xbase + xo[i]) * 4u;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)(xs + (wave + NW * i) * 256), 16, off, 0, 0, 0);
                 }
             }
@@ -225,20 +236,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) a[u][tm] = wl[(c + 2 * u) * BM + tm * 32];
 #pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) b[u][tn] = xl[xb[tn] + (c + 2 * u) * pitch];
+                }
+                if (READS_FIRST) __builtin_amdgcn_sched_barrier(0);   // all 16 LDS reads in flight before the MFMAs
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
-                        float v = xl[xb[tn] + (c + 2 * u) * pitch];
+                        float v = b[u][tn];
                         if (VEC) v = keep[tn] ? v : 0.f;
                         if (LEAKY) v = v > 0.f ? v : v * p.in_slope;
                         b[u][tn] = v;
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][tm], b[u][tn], acc[tm][tn], 0, 0, 0);
+                }
+                if (READS_FIRST) __builtin_amdgcn_sched_barrier(0);
             }
             for (; c < p.ck; c += 2) {
                 float a[TM], b[TN];
@@ -430,12 +446,16 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         launch(kern);
     };
     const bool leaky = p.in_act == RH_ACT_LEAKY;
-    if (vec) {
-        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, true>);
-        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, true>);
+    const bool ctail = (p.C % p.ck) != 0;
+    if (vec && !ctail) {
+        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, true, false>);
+        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, true, false>);
+    } else if (vec) {
+        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, true, true>);
+        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, true, true>);
     } else {
-        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, false>);
-        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, false>);
+        if (leaky) go(conv_igemm_dma_kernel<TM, TN, WM, WN, true, false, true>);
+        else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, false, true>);
     }
     if (int e = rh_check_launch(what)) return e;
     if (p.ksplit > 1) {

@@ -71,6 +71,21 @@ class RAVE(nn.Module):
         self._opts = None
         self._prep = None
 
+    def prepare_weights(self, with_discriminator: bool = False):
+        """Refresh weight norm + packed weights of every conv in two launches (see rave_amd/prep.py);
+        pair with release_weights().  training_step does this itself."""
+        from .prep import WeightPrep
+        if self._prep is None:
+            self._prep = (WeightPrep(nn.ModuleList([self.encoder, self.decoder])), WeightPrep(self.discriminator))
+        self._prep[0].run()
+        if with_discriminator:
+            self._prep[1].run()
+
+    def release_weights(self):
+        if self._prep is not None:
+            self._prep[0].release()
+            self._prep[1].release()
+
     # ---- rave/model.py:226-236
     def configure_optimizers(self):
         gen_p = list(self.encoder.parameters()) + list(self.decoder.parameters())
@@ -120,12 +135,8 @@ class RAVE(nn.Module):
         # all weight-normalised convs: weight norm + MFMA repack refreshed in two launches (plumbing;
         # the reference's weight_norm pre-hooks do the same work layer by layer)
         if batch.is_cuda:
-            from .prep import WeightPrep
-            if self._prep is None:
-                self._prep = (WeightPrep(nn.ModuleList([self.encoder, self.decoder])), WeightPrep(self.discriminator))
-            self._prep[0].run()
-            if self.warmed_up:       # the discriminator only runs (and only then normalises its weights) in phase 2
-                self._prep[1].run()
+            # the discriminator only runs (and only then normalises its weights) in phase 2
+            self.prepare_weights(with_discriminator=bool(self.warmed_up))
         x_raw = batch
         x_raw.requires_grad = True
         batch_size = x_raw.shape[:-2]
@@ -196,9 +207,7 @@ class RAVE(nn.Module):
                 grad_sync(0)
             gen_opt.step()
 
-        if self._prep is not None:
-            self._prep[0].release()
-            self._prep[1].release()
+        self.release_weights()
         self.logged = dict(loss_gen)
         self.logged["loss_dis"] = loss_dis
         return self.logged
