@@ -192,6 +192,50 @@ int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_
 int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
 int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);
 
+/* ---- general 2-D convolution (spectral / descript discriminators) ------------------------------ */
+
+/*
+ * torch.nn.Conv2d with zero padding on (B, C, H, W) tensors, W innermost, groups == 1, followed by the
+ * LeakyReLU the reference puts right after it.  Replaces the Conv2d stacks of
+ *   rave/discriminator.py:23-74  (rectified_2d_conv_block / EncodecConvNet: (9,3) kernels, stride (2,1),
+ *                                 dilation (1,1|2|4); (3,3))
+ *   rave/descript_discriminator.py:22-27,118-184 (WNConv2d; MRD: (3,9) stride (1,2) pad (1,4); (3,3))
+ *   rave/descript_discriminator.py:30-66 (MPD: (5,1) stride (3,1) pad (2,0))
+ *
+ *   y[b,co,ho,wo] = act( bias[co] + sum_{ci,th,tw} w[co,ci,th,tw] * x[b,ci, ho*sh + th*dh - ph, wo*sw + tw*dw - pw] )
+ *
+ * `act` is applied to the OUTPUT (those networks keep the activated tensor as a feature map); the
+ * backward entry points take y and apply act'(y) to dy on the fly (sign(y) == sign(pre-activation)
+ * for a LeakyReLU with positive slope).  Only RH_ACT_NONE / RH_ACT_LEAKY.
+ */
+typedef struct rh_conv2d_desc {
+    int32_t batch;
+    int32_t c_in;
+    int32_t c_out;
+    int32_t h_in, w_in;
+    int32_t h_out, w_out; /* must equal floor((in + 2*pad - dil*(k-1) - 1)/stride) + 1 */
+    int32_t kh, kw;
+    int32_t sh, sw;
+    int32_t dh, dw;
+    int32_t ph, pw;
+    int32_t act;     /* enum rh_act on the output (NONE or LEAKY) */
+    float act_slope;
+} rh_conv2d_desc;
+
+/* Packed weight sizes (floats): which = 0 forward operand, 1 data-gradient operand. */
+int64_t rh_conv2d_packed_floats(const rh_conv2d_desc* d, int which);
+/* w: (c_out, c_in, kh, kw) as torch.nn.Conv2d.weight; wp_bwd may be null. */
+int rh_conv2d_pack_f32(const rh_conv2d_desc* d, const float* w, float* wp_fwd, float* wp_bwd, rh_stream_t stream);
+int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const float* wp_fwd, const float* bias /* may be null */,
+                      float* y, rh_stream_t stream);
+/* dx = conv2d^T(dy * act'(y)); y may be null when act == RH_ACT_NONE. */
+int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* wp_bwd, float* dx,
+                           rh_stream_t stream);
+int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d);
+/* dw (c_out, c_in, kh, kw), dbias (c_out) or null; deterministic (ordered split-K partials in `workspace`). */
+int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x, float* dw,
+                             float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream);
+
 /* ---- spectral distance ("next" item #1 of SURVEY.md section 8f, beside the hot path) ------------- */
 
 /* STFT framing of torchaudio.transforms.Spectrogram(center=True, pad_mode="reflect") as used by

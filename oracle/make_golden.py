@@ -259,6 +259,58 @@ def golden_v1_tiny(name="v1_tiny.pt"):
     print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients", tuple(noise.shape))
 
 
+def _subsample(g, step=257):
+    g = g.reshape(-1)
+    return t(g) if g.numel() <= 200_000 else t(g[::step])
+
+
+def golden_disc2d(name="disc2d_tiny.pt"):
+    """The reference's general-Conv2d discriminators on seeded inputs:
+    (a) rave.discriminator.MultiScaleSpectralDiscriminator + EncodecConvNet (spectral_discriminator.gin:6-17,
+        capacity shrunk to 8, scales [512, 128]);
+    (b) rave.descript_discriminator.DescriptDiscriminator (v3.gin), stereo, periods [3], fft_sizes [256] --
+        channel widths are hard-coded upstream (8.5 M parameters per MPD), so the fixture carries the SEED of
+        rave_oracle.seeded_state_dict instead of the weights.
+    Stored: every feature map, dL/dx and parameter gradients (large ones subsampled every 257th element) of
+    L = sum_f mean(f^2)."""
+    from functools import partial
+    from ref_import import import_reference
+    import_reference()
+    from rave import descript_discriminator as rdd, discriminator as rd
+    out = {}
+
+    def run(model, x, seed, key, store_sd):
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith(".window")}
+        sd = O.seeded_state_dict(shapes, seed)
+        missing = model.load_state_dict(sd, strict=False)
+        assert all(k.endswith(".window") for k in missing.missing_keys) and not missing.unexpected_keys
+        x = x.clone().requires_grad_(True)
+        feats = model(x)
+        flat = [f for net in feats for f in net]
+        loss = sum(f.pow(2).mean() for f in flat)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        out[key] = dict(seed=seed, shapes=shapes, x=t(x), loss=t(loss), dx=t(x.grad),
+                        features=[[t(f) for f in net] for net in feats],
+                        grads={k: _subsample(p.grad) for k, p in model.named_parameters()},
+                        grad_step=257)
+        if store_sd:
+            out[key]["state_dict"] = {k: t(v) for k, v in sd.items()}
+        print(key, "loss", float(loss), "features", [len(n) for n in feats],
+              "params", sum(p.numel() for p in model.parameters()))
+
+    torch.manual_seed(0)
+    enc = rd.MultiScaleSpectralDiscriminator(scales=[512, 128], convnet=partial(rd.EncodecConvNet, capacity=8),
+                                             n_channels=1)
+    run(enc, O.synthetic_batch(2, 1, 4096, seed=31), 101, "encodec", True)
+    out["encodec"]["config"] = dict(scales=[512, 128], capacity=8, n_channels=1)
+    des = rdd.DescriptDiscriminator(periods=[3], fft_sizes=[256], n_channels=2)
+    run(des, O.synthetic_batch(1, 2, 2048, seed=32), 202, "descript", False)
+    out["descript"]["config"] = dict(periods=[3], fft_sizes=[256], n_channels=2)
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
@@ -267,3 +319,4 @@ if __name__ == "__main__":
     golden_v3_gen_tiny()
     golden_v2_small_tiny()
     golden_v1_tiny()
+    golden_disc2d()

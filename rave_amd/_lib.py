@@ -27,6 +27,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class Conv2dDesc(C.Structure):
+    """Mirror of ``rh_conv2d_desc`` (include/rave_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "c_in", "c_out", "h_in", "w_in", "h_out", "w_out", "kh", "kw", "sh", "sw", "dh", "dw", "ph", "pw",
+        "act")] + [("act_slope", C.c_float)]
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -35,6 +42,7 @@ def _load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     D = C.POINTER(ConvDesc)
+    D2 = C.POINTER(Conv2dDesc)
     sig = {
         "rh_version": ([], C.c_int),
         "rh_last_error": ([], C.c_char_p),
@@ -53,6 +61,12 @@ def _load() -> C.CDLL:
         "rh_conv1d_bwd_data_workspace_bytes": ([D], I64),
         "rh_conv1d_workspace_bytes": ([D], I64),
         "rh_conv1d_bwd_weight_f32": ([D, P, P, P, P, P, P, I64, P], C.c_int),
+        "rh_conv2d_packed_floats": ([D2, C.c_int], I64),
+        "rh_conv2d_pack_f32": ([D2, P, P, P, P], C.c_int),
+        "rh_conv2d_fwd_f32": ([D2, P, P, P, P, P], C.c_int),
+        "rh_conv2d_bwd_data_f32": ([D2, P, P, P, P, P], C.c_int),
+        "rh_conv2d_workspace_bytes": ([D2], I64),
+        "rh_conv2d_bwd_weight_f32": ([D2, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_pqmf_analysis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
         "rh_pqmf_analysis_bwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
         "rh_pqmf_synthesis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),

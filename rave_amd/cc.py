@@ -176,6 +176,20 @@ class Conv2dK1(nn.Conv2d):
         return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg, prepacked=getattr(self, "_prepacked", None))
 
 
+class Conv2d(nn.Conv2d):
+    """torch.nn.Conv2d (zero padding, groups == 1, any kernel / stride / dilation) on the HIP 2-D kernels
+    (rh_conv2d_*_f32).  ``act`` is applied to the OUTPUT: the spectral / descript discriminators keep
+    LeakyReLU(conv(x)) as a feature map (rave/discriminator.py:50, rave/descript_discriminator.py:27)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.groups != 1 or self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise NotImplementedError("rave_amd.cc.Conv2d: groups / padding_mode")
+
+    def forward(self, x, act: int = ACT_NONE, slope: float = 0.2):
+        return ops.conv2d(x, _effective_weight(self), self.bias, self.stride, self.padding, self.dilation, act, slope)
+
+
 class CachedSequential(nn.Sequential):
     def __init__(self, *args, **kwargs):
         cumulative_delay = kwargs.pop("cumulative_delay", 0)

@@ -1,0 +1,681 @@
+// General 2-D convolution (zero padding, stride, dilation in both dims, groups == 1) on the
+// f32-input matrix cores, for the Conv2d stacks of the spectral discriminators:
+//   rave/discriminator.py:23-74 (EncodecConvNet), rave/descript_discriminator.py:30-66,118-184 (MPD, MRD).
+//
+// Same implicit-GEMM view as the 1-D kernels (M = out channels, N = output positions, K = (tap,
+// in channel)) but the column tile is a 2-D block of TR x TQ output positions (x nb batch items when the
+// plane is small), and the staged B operand is the 2-D input patch that block needs:
+//   PH = (TR-1)*is_h + tap span_h + 1 rows,  PW = (TQ-1)*is_w + tap span_w + 1 columns,
+// zero-filled by (h, w) coordinates -- all four paddings come out of the staging, the im2col matrix is
+// never materialised and a tap is just a constant LDS offset.  The data gradient is the same kernel run
+// per output phase (alpha_h < sh, alpha_w < sw), with dy * act'(y) formed while staging.
+// The weight gradient reduces over 2-D chunks (rk x wk positions of dy) per batch item; split-K partials
+// + ordered reduction keep it bitwise deterministic.
+#include <mutex>
+#include "conv_params.hpp"
+
+namespace {
+
+constexpr int kPh2 = 8;   // max sh*sw
+
+struct Conv2P {
+    const float* in;
+    const float* wp;
+    float* out;
+    const float* bias;
+    const float* in_mul;            // staged value *= act'(in_mul[same index])   (data gradient) or null
+    int B, C, M, Mp;
+    int in_h, in_w, out_h, out_w;
+    int rows, qcols;                // per-phase output grid
+    int is_h, is_w, os_h, os_w;
+    int TQ, TR, tq_shift, tr_shift, nb, tiles_q, tiles_r;
+    int PH, PW, PWp, chp;           // staged patch per (batch item, channel): PH x PW, row pitch PWp, plane pitch chp
+    int ck, wlds_floats;
+    int mul_act, epi_act;
+    float mul_slope, epi_slope;
+    int nphase;
+    int ph_oph_h[kPh2], ph_oph_w[kPh2], ph_ntaps[kPh2], ph_tap0[kPh2], ph_minh[kPh2], ph_minw[kPh2];
+    long ph_wofs[kPh2];
+    int offh[kMaxTaps], offw[kMaxTaps];
+};
+
+struct Wgrad2P {
+    const float* R;                 // dy  [B][M][r_h][r_w]
+    const float* Rmul;              // y (same shape) or null: R *= act'(y)
+    const float* S;                 // x   [B][C][s_h][s_w]
+    float* out;                     // [Z][M][C*T]
+    int B, M, C, T;
+    int r_h, r_w, s_h, s_w, is_h, is_w;
+    int rk, wk, wk_shift;           // dy chunk: rk rows x wk columns (wk = power of two >= 2)
+    int chunks_r, chunks_w, total_chunks, chunks_per_z;
+    int pr, PH, PW, PWp, chp, nc_max;
+    int minh, minw;
+    int r_act;
+    float r_slope;
+    int offh[kMaxTaps], offw[kMaxTaps];
+};
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv2d_igemm_kernel(const Conv2P p) {
+    constexpr int BM = TM * WM * 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int NW = WM * WN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w_lds = smem;
+    float* x_lds = smem + p.wlds_floats;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    const int phase = blockIdx.z;
+    const int ntaps = p.ph_ntaps[phase];
+    const int tap0 = p.ph_tap0[phase];
+    const int minh = p.ph_minh[phase], minw = p.ph_minw[phase];
+    const float* __restrict__ wp = p.wp + p.ph_wofs[phase];
+
+    int bx = blockIdx.x;
+    const int tq = bx % p.tiles_q;
+    bx /= p.tiles_q;
+    const int tr = bx % p.tiles_r;
+    const int bt = bx / p.tiles_r;
+    const int b0 = bt * p.nb, r0 = tr * p.TR, q0 = tq * p.TQ;
+    const int m0 = blockIdx.y * BM;
+    const int h0 = r0 * p.is_h + minh, w0 = q0 * p.is_w + minw;
+
+    int xb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = (wn * TN + tn) * 32 + j;
+        const int ql = col & (p.TQ - 1);
+        const int rl = (col >> p.tq_shift) & (p.TR - 1);
+        const int bl = col >> (p.tq_shift + p.tr_shift);
+        xb[tn] = (bl * p.ck + kh) * p.chp + rl * p.is_h * p.PWp + ql * p.is_w;
+    }
+    const int arow = wm * TM * 32 + j + kh * BM;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    for (int c0 = 0; c0 < p.C && ntaps > 0; c0 += p.ck) {
+        __syncthreads();
+        // ---- stage the 2-D input patches (zero fill by coordinates = all four paddings) ----
+        const int nrows = p.nb * p.ck * p.PH;
+        for (int row = wave; row < nrows; row += NW) {
+            const int bc = row / p.PH, phh = row - bc * p.PH;
+            const int bl = bc / p.ck, c = bc - bl * p.ck;
+            const int b = b0 + bl, ch = c0 + c, h = h0 + phh;
+            float* dst = x_lds + bc * p.chp + phh * p.PWp;
+            const bool ok = b < p.B && ch < p.C && h >= 0 && h < p.in_h;
+            const long base = (((long)b * p.C + ch) * p.in_h + h) * p.in_w;
+            for (int w = lane; w < p.PW; w += 64) {
+                const int gw = w0 + w;
+                float v = 0.f;
+                if (ok && gw >= 0 && gw < p.in_w) {
+                    v = p.in[base + gw];
+                    if (p.in_mul) v *= rh_act_grad(p.in_mul[base + gw], p.mul_act, p.mul_slope, 0.f);
+                }
+                dst[w] = v;
+            }
+        }
+        // ---- stage the weight tile [tap][c][BM] ----
+        constexpr int V = BM / 4;
+        const int wrows = ntaps * p.ck;
+        for (int e = tid; e < wrows * V; e += NT) {
+            const int kr = e / V, v4 = e - kr * V;
+            const int t = kr / p.ck, c = kr - t * p.ck;
+            const int ch = c0 + c;
+            const int m = m0 + v4 * 4;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (ch < p.C && m < p.Mp)
+                val = *reinterpret_cast<const f32x4*>(wp + ((long)t * p.C + ch) * p.Mp + m);
+            *reinterpret_cast<f32x4*>(w_lds + kr * BM + v4 * 4) = val;
+        }
+        __syncthreads();
+        // ---- MFMA over (tap, channel pair) ----
+        for (int t = 0; t < ntaps; ++t) {
+            const int toff = (p.offh[tap0 + t] - minh) * p.PWp + (p.offw[tap0 + t] - minw);
+            const float* wl = w_lds + t * p.ck * BM + arow;
+            const float* xl = x_lds + toff;
+            for (int c = 0; c < p.ck; c += 2) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm] = wl[c * BM + tm * 32];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) b[tn] = xl[xb[tn] + c * p.chp];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + output activation ----
+    const int oph_h = p.ph_oph_h[phase], oph_w = p.ph_oph_w[phase];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = (wn * TN + tn) * 32 + j;
+        const int ql = col & (p.TQ - 1);
+        const int rl = (col >> p.tq_shift) & (p.TR - 1);
+        const int bl = col >> (p.tq_shift + p.tr_shift);
+        const int r = r0 + rl, q = q0 + ql, b = b0 + bl;
+        if (r >= p.rows || q >= p.qcols || b >= p.B) continue;
+        const int orow = r * p.os_h + oph_h, ocol = q * p.os_w + oph_w;
+        if (orow >= p.out_h || ocol >= p.out_w) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = m0 + (wm * TM + tm) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+                if (m < p.M) {
+                    const long idx = (((long)b * p.M + m) * p.out_h + orow) * p.out_w + ocol;
+                    float v = acc[tm][tn][rr];
+                    if (p.bias) v += p.bias[m];
+                    p.out[idx] = rh_act_apply(v, p.epi_act, p.epi_slope, 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void wgrad2d_kernel(const Wgrad2P p) {
+    constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
+    constexpr int NW = WM * WN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* r_lds = smem;                 // [BM][pr]
+    float* s_lds = smem + BM * p.pr;     // [nc_max][chp]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int m0 = blockIdx.y * BM, col0 = blockIdx.x * BN, z = blockIdx.z;
+    const int ncols = p.C * p.T;
+    const int c_lo = col0 / p.T;
+
+    int sb[TN], ar[TM];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int col = col0 + (wn * TN + tn) * 32 + j;
+        col = min(col, ncols - 1);
+        const int c = col / p.T, t = col - c * p.T;
+        sb[tn] = (c - c_lo) * p.chp + (p.offh[t] - p.minh) * p.PWp + (p.offw[t] - p.minw) + kh * p.is_w;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) ar[tm] = ((wm * TM + tm) * 32 + j) * p.pr + kh;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int kelems = p.rk * p.wk;
+    const int ch0 = z * p.chunks_per_z;
+    const int ch1 = min(ch0 + p.chunks_per_z, p.total_chunks);
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int cw = ch % p.chunks_w;
+        const int t2 = ch / p.chunks_w;
+        const int cr = t2 % p.chunks_r;
+        const int b = t2 / p.chunks_r;
+        const int hr0 = cr * p.rk, wc0 = cw * p.wk;
+        __syncthreads();
+        for (int r = wave; r < BM; r += NW) {
+            const int m = m0 + r;
+            float* dst = r_lds + r * p.pr;
+            for (int e = lane; e < kelems; e += 64) {
+                const int rr = e >> p.wk_shift, ww = e & (p.wk - 1);
+                const int h = hr0 + rr, w = wc0 + ww;
+                float v = 0.f;
+                if (m < p.M && h < p.r_h && w < p.r_w) {
+                    const long idx = (((long)b * p.M + m) * p.r_h + h) * p.r_w + w;
+                    v = p.R[idx];
+                    if (p.Rmul) v *= rh_act_grad(p.Rmul[idx], p.r_act, p.r_slope, 0.f);
+                }
+                dst[e] = v;
+            }
+        }
+        const int h0 = hr0 * p.is_h + p.minh, w0 = wc0 * p.is_w + p.minw;
+        const int srows = p.nc_max * p.PH;
+        for (int row = wave; row < srows; row += NW) {
+            const int cc = row / p.PH, phh = row - cc * p.PH;
+            const int c = c_lo + cc, h = h0 + phh;
+            const bool ok = c < p.C && h >= 0 && h < p.s_h;
+            const long base = (((long)b * p.C + c) * p.s_h + h) * p.s_w;
+            float* dst = s_lds + cc * p.chp + phh * p.PWp;
+            for (int w = lane; w < p.PW; w += 64) {
+                const int gw = w0 + w;
+                dst[w] = (ok && gw >= 0 && gw < p.s_w) ? p.S[base + gw] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int rr = 0; rr < p.rk; ++rr) {
+            const float* rl = r_lds + rr * p.wk;
+            const float* sl = s_lds + rr * p.is_h * p.PWp;
+            for (int ww = 0; ww < p.wk; ww += 2) {
+                float a[TM], bb[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm] = rl[ar[tm] + ww];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bb[tn] = sl[sb[tn] + ww * p.is_w];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+    float* out = p.out + (long)z * p.M * ncols;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = col0 + (wn * TN + tn) * 32 + j;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < p.M) out[(long)m * ncols + col] = acc[tm][tn][r];
+            }
+    }
+}
+
+// dbias[m] = sum_{b,h,w} dy * act'(y)   (one block per channel, fixed reduction order)
+__global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ db, int B, int M, long plane, int act,
+                                                          float slope) {
+    __shared__ float red[256];
+    const int m = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const long base = ((long)b * M + m) * plane;
+        for (long e = threadIdx.x; e < plane; e += 256) {
+            float v = dy[base + e];
+            if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
+            s += v;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[m] = red[0];
+}
+
+inline int round32(int m) { return (m + 31) & ~31; }
+inline int pow2ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int validate2(const rh_conv2d_desc* d) {
+    RH_REQUIRE(d, RH_ERR_INVALID, "conv2d: null descriptor");
+    RH_REQUIRE(d->batch >= 0 && d->c_in > 0 && d->c_out > 0 && d->h_in > 0 && d->w_in > 0 && d->h_out > 0 &&
+                   d->w_out > 0,
+               RH_ERR_INVALID, "conv2d: bad sizes");
+    RH_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->sh >= 1 && d->sw >= 1 && d->dh >= 1 && d->dw >= 1 && d->ph >= 0 &&
+                   d->pw >= 0,
+               RH_ERR_INVALID, "conv2d: kernel/stride/dilation must be >= 1, padding >= 0");
+    RH_REQUIRE(d->kh * d->kw <= kMaxTaps, RH_ERR_UNSUPPORTED, "conv2d: %d x %d taps > %d", d->kh, d->kw, kMaxTaps);
+    RH_REQUIRE(d->sh * d->sw <= kPh2, RH_ERR_UNSUPPORTED, "conv2d: stride %d x %d > %d phases", d->sh, d->sw, kPh2);
+    RH_REQUIRE(d->act == RH_ACT_NONE || d->act == RH_ACT_LEAKY, RH_ERR_UNSUPPORTED,
+               "conv2d: output activation must be none or leaky");
+    const int ho = (d->h_in + 2 * d->ph - d->dh * (d->kh - 1) - 1) / d->sh + 1;
+    const int wo = (d->w_in + 2 * d->pw - d->dw * (d->kw - 1) - 1) / d->sw + 1;
+    RH_REQUIRE(d->h_in + 2 * d->ph - d->dh * (d->kh - 1) - 1 >= 0 && d->w_in + 2 * d->pw - d->dw * (d->kw - 1) - 1 >= 0,
+               RH_ERR_INVALID, "conv2d: kernel larger than the padded input");
+    RH_REQUIRE(ho == d->h_out && wo == d->w_out, RH_ERR_INVALID, "conv2d: (h_out, w_out) = (%d, %d), geometry gives (%d, %d)",
+               d->h_out, d->w_out, ho, wo);
+    RH_REQUIRE((int64_t)d->h_in * d->w_in < (1ll << 30) && (int64_t)d->h_out * d->w_out < (1ll << 30), RH_ERR_UNSUPPORTED,
+               "conv2d: plane too large");
+    return RH_OK;
+}
+
+struct Plan2 {
+    int nphase = 0;
+    int oph_h[kPh2], oph_w[kPh2], ntaps[kPh2], tap0[kPh2], minh[kPh2], minw[kPh2], maxh[kPh2], maxw[kPh2];
+    int nslots = 0;
+    int kk[kMaxTaps], offh[kMaxTaps], offw[kMaxTaps];
+};
+
+// which: 0 = forward operand, 1 = data-gradient operand
+void build_plan2(const rh_conv2d_desc* d, int which, Plan2* pl) {
+    Plan2& t = *pl;
+    if (which == 0) {
+        t.nphase = 1;
+        t.oph_h[0] = t.oph_w[0] = 0;
+        t.tap0[0] = 0;
+        for (int th = 0; th < d->kh; ++th)
+            for (int tw = 0; tw < d->kw; ++tw) {
+                t.kk[t.nslots] = th * d->kw + tw;
+                t.offh[t.nslots] = th * d->dh - d->ph;
+                t.offw[t.nslots] = tw * d->dw - d->pw;
+                ++t.nslots;
+            }
+        t.ntaps[0] = t.nslots;
+    } else {
+        for (int ah = 0; ah < d->sh; ++ah)
+            for (int aw = 0; aw < d->sw; ++aw) {
+                const int ph = t.nphase++;
+                t.oph_h[ph] = ah;
+                t.oph_w[ph] = aw;
+                t.tap0[ph] = t.nslots;
+                int n = 0;
+                for (int th = 0; th < d->kh; ++th) {
+                    const int nh = ah + d->ph - th * d->dh;
+                    if (nh % d->sh != 0) continue;
+                    for (int tw = 0; tw < d->kw; ++tw) {
+                        const int nw = aw + d->pw - tw * d->dw;
+                        if (nw % d->sw != 0) continue;
+                        t.kk[t.nslots] = th * d->kw + tw;
+                        t.offh[t.nslots] = nh / d->sh;
+                        t.offw[t.nslots] = nw / d->sw;
+                        ++t.nslots;
+                        ++n;
+                    }
+                }
+                t.ntaps[ph] = n;
+            }
+    }
+    for (int ph = 0; ph < t.nphase; ++ph) {
+        t.minh[ph] = t.maxh[ph] = t.minw[ph] = t.maxw[ph] = 0;
+        for (int i = 0; i < t.ntaps[ph]; ++i) {
+            const int oh = t.offh[t.tap0[ph] + i], ow = t.offw[t.tap0[ph] + i];
+            if (i == 0 || oh < t.minh[ph]) t.minh[ph] = oh;
+            if (i == 0 || oh > t.maxh[ph]) t.maxh[ph] = oh;
+            if (i == 0 || ow < t.minw[ph]) t.minw[ph] = ow;
+            if (i == 0 || ow > t.maxw[ph]) t.maxw[ph] = ow;
+        }
+    }
+}
+
+void fill_common(const Plan2& t, Conv2P* p, int C, int M) {
+    p->C = C;
+    p->M = M;
+    p->Mp = round32(M);
+    p->nphase = t.nphase;
+    long wofs = 0;
+    for (int ph = 0; ph < t.nphase; ++ph) {
+        p->ph_oph_h[ph] = t.oph_h[ph];
+        p->ph_oph_w[ph] = t.oph_w[ph];
+        p->ph_ntaps[ph] = t.ntaps[ph];
+        p->ph_tap0[ph] = t.tap0[ph];
+        p->ph_minh[ph] = t.minh[ph];
+        p->ph_minw[ph] = t.minw[ph];
+        p->ph_wofs[ph] = wofs;
+        wofs += (long)t.ntaps[ph] * C * p->Mp;
+    }
+    for (int i = 0; i < t.nslots; ++i) {
+        p->offh[i] = t.offh[i];
+        p->offw[i] = t.offw[i];
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch2(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what) {
+    constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
+    p.TQ = pow2ceil(p.qcols) < BN ? pow2ceil(p.qcols) : BN;
+    const int tr_cap = BN / p.TQ;
+    p.TR = pow2ceil(p.rows) < tr_cap ? pow2ceil(p.rows) : tr_cap;
+    p.nb = BN / (p.TQ * p.TR);
+    p.tq_shift = __builtin_ctz(p.TQ);
+    p.tr_shift = __builtin_ctz(p.TR);
+    p.tiles_q = rh_cdiv(p.qcols, p.TQ);
+    p.tiles_r = rh_cdiv(p.rows, p.TR);
+    int span_h = 0, span_w = 0, maxtaps = 1;
+    for (int i = 0; i < t.nphase; ++i) {
+        span_h = span_h > t.maxh[i] - t.minh[i] ? span_h : t.maxh[i] - t.minh[i];
+        span_w = span_w > t.maxw[i] - t.minw[i] ? span_w : t.maxw[i] - t.minw[i];
+        maxtaps = maxtaps > t.ntaps[i] ? maxtaps : t.ntaps[i];
+    }
+    p.PH = (p.TR - 1) * p.is_h + span_h + 1;
+    p.PW = (p.TQ - 1) * p.is_w + span_w + 1;
+    p.PWp = p.PW | 1;
+    p.chp = (p.PH * p.PWp) | 1;
+    const int per_ch = maxtaps * BM + p.nb * p.chp;
+    int ck = (15 * 1024) / per_ch;
+    ck &= ~1;
+    if (ck > 32) ck = 32;
+    if (ck < 2) ck = 2;
+    const int cmax = (p.C + 1) & ~1;
+    if (ck > cmax) ck = cmax;
+    p.ck = ck;
+    p.wlds_floats = maxtaps * ck * BM;
+    const size_t lds = sizeof(float) * ((size_t)p.wlds_floats + (size_t)p.nb * ck * p.chp);
+    RH_REQUIRE(lds <= 160 * 1024, RH_ERR_UNSUPPORTED, "%s: tile needs %zu B of LDS", what, lds);
+    auto kern = conv2d_igemm_kernel<TM, TN, WM, WN>;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+    });
+    const long gx = (long)rh_cdiv(p.B, p.nb) * p.tiles_r * p.tiles_q;
+    RH_REQUIRE(gx < (1l << 31), RH_ERR_UNSUPPORTED, "%s: grid too large", what);
+    dim3 grid((unsigned)gx, rh_cdiv(p.M, BM), p.nphase);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+    return rh_check_launch(what);
+}
+
+int launch_conv2(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what) {
+    if (p.B <= 0) return RH_OK;
+    if (p.M <= 32) return launch2<1, 2, 1, 4>(p, t, stream, what);
+    if (p.M <= 64) return launch2<2, 1, 1, 4>(p, t, stream, what);
+    if (p.M % 96 == 0) return launch2<3, 1, 1, 4>(p, t, stream, what);
+    return launch2<2, 2, 2, 2>(p, t, stream, what);
+}
+
+struct W2Plan {
+    int bm, bn, Z;
+    size_t lds;
+};
+
+W2Plan plan_w2(Wgrad2P& p) {
+    W2Plan w{};
+    if (p.M <= 32) { w.bm = 32; w.bn = 256; }
+    else if (p.M <= 64) { w.bm = 64; w.bn = 128; }
+    else if (p.M % 96 == 0) { w.bm = 96; w.bn = 128; }
+    else { w.bm = 128; w.bn = 128; }
+    const int ncols = p.C * p.T;
+    p.nc_max = (w.bn - 1) / p.T + 2;
+    if (p.nc_max > p.C) p.nc_max = p.C;
+    p.wk = pow2ceil(p.r_w) < 64 ? pow2ceil(p.r_w) : 64;
+    if (p.wk < 2) p.wk = 2;
+    p.wk_shift = __builtin_ctz(p.wk);
+    int span_h = 0, span_w = 0, minh = 0, minw = 0;
+    for (int t = 0; t < p.T; ++t) {
+        if (t == 0 || p.offh[t] < minh) minh = p.offh[t];
+        if (t == 0 || p.offw[t] < minw) minw = p.offw[t];
+    }
+    for (int t = 0; t < p.T; ++t) {
+        span_h = span_h > p.offh[t] - minh ? span_h : p.offh[t] - minh;
+        span_w = span_w > p.offw[t] - minw ? span_w : p.offw[t] - minw;
+    }
+    p.minh = minh;
+    p.minw = minw;
+    p.PW = (p.wk - 1) * p.is_w + span_w + 1;
+    p.PWp = p.PW | 1;
+    int rk = 256 / p.wk > 4 ? 256 / p.wk : 4;       // aim at ~256 reduction elements per chunk
+    if (rk > pow2ceil(p.r_h)) rk = pow2ceil(p.r_h);
+    for (;; rk >>= 1) {
+        p.rk = rk;
+        p.PH = (rk - 1) * p.is_h + span_h + 1;
+        p.chp = (p.PH * p.PWp) | 1;
+        p.pr = rk * p.wk + 2;
+        w.lds = sizeof(float) * ((size_t)w.bm * p.pr + (size_t)p.nc_max * p.chp);
+        if (w.lds <= 80 * 1024 || rk == 1) break;
+    }
+    p.chunks_r = rh_cdiv(p.r_h, p.rk);
+    p.chunks_w = rh_cdiv(p.r_w, p.wk);
+    p.total_chunks = p.B * p.chunks_r * p.chunks_w;
+    const int bxy = rh_cdiv(ncols, w.bn) * rh_cdiv(p.M, w.bm);
+    int Z = 1024 / (bxy > 0 ? bxy : 1);
+    if (Z > p.total_chunks / 4) Z = p.total_chunks / 4;     // at least 4 chunks per slice
+    if (Z < 1) Z = 1;
+    p.chunks_per_z = rh_cdiv(p.total_chunks, Z);
+    w.Z = rh_cdiv(p.total_chunks, p.chunks_per_z);
+    return w;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_w2(const Wgrad2P& p, const W2Plan& w, hipStream_t stream) {
+    constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
+    RH_REQUIRE(w.lds <= 160 * 1024, RH_ERR_UNSUPPORTED, "conv2d_bwd_weight: tile needs %zu B of LDS", w.lds);
+    auto kern = wgrad2d_kernel<TM, TN, WM, WN>;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+    });
+    dim3 grid(rh_cdiv(p.C * p.T, BN), rh_cdiv(p.M, BM), w.Z);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), w.lds, stream, p);
+    return rh_check_launch("conv2d_bwd_weight");
+}
+
+void fill_w2(const rh_conv2d_desc* d, Wgrad2P* p) {
+    *p = Wgrad2P{};
+    p->B = d->batch; p->M = d->c_out; p->C = d->c_in; p->T = d->kh * d->kw;
+    p->r_h = d->h_out; p->r_w = d->w_out; p->s_h = d->h_in; p->s_w = d->w_in;
+    p->is_h = d->sh; p->is_w = d->sw;
+    p->r_act = d->act; p->r_slope = d->act_slope;
+    for (int th = 0; th < d->kh; ++th)
+        for (int tw = 0; tw < d->kw; ++tw) {
+            p->offh[th * d->kw + tw] = th * d->dh - d->ph;
+            p->offw[th * d->kw + tw] = tw * d->dw - d->pw;
+        }
+}
+
+int fill_pack2(const rh_conv2d_desc* d, int which, const float* w, float* wp, PackP* p) {
+    *p = PackP{};
+    if (!wp) return RH_OK;
+    Plan2 t;
+    build_plan2(d, which, &t);
+    p->w = w; p->scale = nullptr; p->wp = wp;
+    p->C = which == 0 ? d->c_in : d->c_out;
+    p->M = which == 0 ? d->c_out : d->c_in;
+    p->Mp = round32(p->M);
+    p->k = d->kh * d->kw;
+    p->m_major = which == 0 ? 1 : 0;      // w[co][ci][kk]: forward m = co (m-major), data gradient m = ci (c-major)
+    p->total = (long)t.nslots * p->C * p->Mp;
+    for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
+    return RH_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t rh_conv2d_packed_floats(const rh_conv2d_desc* d, int which) {
+    if (validate2(d)) return -1;
+    const int64_t M = which == 0 ? d->c_out : d->c_in;
+    const int64_t C = which == 0 ? d->c_in : d->c_out;
+    return (int64_t)d->kh * d->kw * C * round32((int)M);
+}
+
+extern "C" int rh_conv2d_pack_f32(const rh_conv2d_desc* d, const float* w, float* wp_fwd, float* wp_bwd,
+                                  rh_stream_t stream) {
+    if (int e = validate2(d)) return e;
+    RH_REQUIRE(w, RH_ERR_INVALID, "conv2d_pack: null weight");
+    PackP a, b;
+    if (int e = fill_pack2(d, 0, w, wp_fwd, &a)) return e;
+    if (int e = fill_pack2(d, 1, w, wp_bwd, &b)) return e;
+    return rh_pack_launch(a, b, (hipStream_t)stream, "conv2d_pack");
+}
+
+extern "C" int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const float* wp_fwd, const float* bias,
+                                 float* y, rh_stream_t stream) {
+    if (int e = validate2(d)) return e;
+    if (d->batch == 0) return RH_OK;
+    RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv2d_fwd: null pointer");
+    Plan2 t;
+    build_plan2(d, 0, &t);
+    Conv2P p{};
+    fill_common(t, &p, d->c_in, d->c_out);
+    p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.in_mul = nullptr;
+    p.B = d->batch;
+    p.in_h = d->h_in; p.in_w = d->w_in; p.out_h = d->h_out; p.out_w = d->w_out;
+    p.rows = d->h_out; p.qcols = d->w_out;
+    p.is_h = d->sh; p.is_w = d->sw; p.os_h = 1; p.os_w = 1;
+    p.mul_act = RH_ACT_NONE; p.mul_slope = 0.f;
+    p.epi_act = d->act; p.epi_slope = d->act_slope;
+    return launch_conv2(p, t, (hipStream_t)stream, "conv2d_fwd");
+}
+
+extern "C" int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* wp_bwd,
+                                      float* dx, rh_stream_t stream) {
+    if (int e = validate2(d)) return e;
+    if (d->batch == 0) return RH_OK;
+    RH_REQUIRE(dy && wp_bwd && dx, RH_ERR_INVALID, "conv2d_bwd_data: null pointer");
+    RH_REQUIRE(d->act == RH_ACT_NONE || y, RH_ERR_INVALID, "conv2d_bwd_data: the output activation needs y");
+    Plan2 t;
+    build_plan2(d, 1, &t);
+    Conv2P p{};
+    fill_common(t, &p, d->c_out, d->c_in);
+    p.in = dy; p.wp = wp_bwd; p.out = dx; p.bias = nullptr;
+    p.in_mul = d->act == RH_ACT_NONE ? nullptr : y;
+    p.B = d->batch;
+    p.in_h = d->h_out; p.in_w = d->w_out; p.out_h = d->h_in; p.out_w = d->w_in;
+    p.rows = rh_cdiv(d->h_in, d->sh); p.qcols = rh_cdiv(d->w_in, d->sw);
+    p.is_h = 1; p.is_w = 1; p.os_h = d->sh; p.os_w = d->sw;
+    p.mul_act = d->act; p.mul_slope = d->act_slope;
+    p.epi_act = RH_ACT_NONE; p.epi_slope = 0.f;
+    return launch_conv2(p, t, (hipStream_t)stream, "conv2d_bwd_data");
+}
+
+extern "C" int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d) {
+    if (validate2(d)) return -1;
+    if (d->batch == 0) return 0;
+    Wgrad2P p;
+    fill_w2(d, &p);
+    const W2Plan w = plan_w2(p);
+    return w.Z > 1 ? (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x,
+                                        float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                                        rh_stream_t stream_) {
+    if (int e = validate2(d)) return e;
+    hipStream_t stream = (hipStream_t)stream_;
+    RH_REQUIRE(dw && (d->batch == 0 || (dy && x)), RH_ERR_INVALID, "conv2d_bwd_weight: null pointer");
+    RH_REQUIRE(d->act == RH_ACT_NONE || d->batch == 0 || y, RH_ERR_INVALID,
+               "conv2d_bwd_weight: the output activation needs y");
+    const long nw = (long)d->c_out * d->c_in * d->kh * d->kw;
+    if (d->batch == 0) {
+        if (hipError_t e = hipMemsetAsync(dw, 0, nw * sizeof(float), stream)) return (int)e;
+        if (dbias)
+            if (hipError_t e = hipMemsetAsync(dbias, 0, d->c_out * sizeof(float), stream)) return (int)e;
+        return RH_OK;
+    }
+    const float* ymul = d->act == RH_ACT_NONE ? nullptr : y;
+    if (dbias) {
+        hipLaunchKernelGGL(bias_grad2d_kernel, dim3(d->c_out), dim3(256), 0, stream, dy, ymul, dbias, d->batch,
+                           d->c_out, (long)d->h_out * d->w_out, d->act, d->act_slope);
+        if (int e = rh_check_launch("conv2d_bias_grad")) return e;
+    }
+    Wgrad2P p;
+    fill_w2(d, &p);
+    p.R = dy; p.Rmul = ymul; p.S = x;
+    const W2Plan w = plan_w2(p);
+    const int64_t need = w.Z > 1 ? (int64_t)w.Z * nw * (int64_t)sizeof(float) : 0;
+    RH_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), RH_ERR_WORKSPACE,
+               "conv2d_bwd_weight: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
+    p.out = w.Z > 1 ? (float*)workspace : dw;
+    int e;
+    if (w.bm == 32) e = launch_w2<1, 2, 1, 4>(p, w, stream);
+    else if (w.bm == 64) e = launch_w2<2, 1, 1, 4>(p, w, stream);
+    else if (w.bm == 96) e = launch_w2<3, 1, 1, 4>(p, w, stream);
+    else e = launch_w2<2, 2, 2, 2>(p, w, stream);
+    if (e) return e;
+    if (w.Z > 1) return rh_reduce_partials_launch((const float*)workspace, dw, nw, w.Z, stream, "conv2d_bwd_weight_reduce");
+    return RH_OK;
+}

@@ -138,16 +138,6 @@ void plan_to_params(const TapPlan& t, ConvP* p) {
     for (int i = 0; i < t.nslots; ++i) p->off[i] = t.off[i];
 }
 
-struct PackP {
-    const float* w;
-    const float* scale;   // per dim-0 slice (weight-norm g/||v||) or null
-    float* wp;
-    long total;           // nslots * C * Mp
-    int C, M, Mp, k;
-    int m_major;
-    int kk[kMaxTaps];
-};
-
 __device__ __forceinline__ void pack_one_elem(const PackP& p, long e) {
     const int m = (int)(e % p.Mp);
     const long r = e / p.Mp;
@@ -197,6 +187,13 @@ int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float
 }
 
 }  // namespace
+
+int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what) {
+    const long total = a.total + b.total;
+    if (total == 0) return RH_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, a, b);
+    return rh_check_launch(what);
+}
 
 int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p) {
     if (int e = validate(d)) return e;

@@ -75,6 +75,19 @@ struct WgradP {
     int off[kMaxTaps];
 };
 
+// Weight repack: wp[slot][c][Mp] = scale * w[src(m, c, kk[slot])]   (one slot per (phase, tap))
+struct PackP {
+    const float* w;
+    const float* scale;   // per dim-0 slice (weight-norm g/||v||) or null
+    float* wp;
+    long total;           // nslots * C * Mp   (0 = nothing to do)
+    int C, M, Mp, k;      // k = taps per (m, c) pair in the source tensor
+    int m_major;          // source index = (m*C + c)*k + kk, else (c*M + m)*k + kk
+    int kk[kMaxTaps];
+};
+int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what);
+int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what);
+
 int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p);
 int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p);
 int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what, void* ws = nullptr, int64_t ws_bytes = 0);

@@ -591,3 +591,9 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     }
     return RH_OK;
 }
+
+int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what) {
+    if (n <= 0) return RH_OK;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 256)), dim3(256), 0, stream, part, out, n, Z);
+    return rh_check_launch(what);
+}

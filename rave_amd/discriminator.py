@@ -106,3 +106,89 @@ class CombineDiscriminators(nn.Module):
         for disc in self.discriminators:
             features.extend(disc(x))
         return features
+
+
+# --------------------------------------------------------------------------- spectral discriminator
+class Spectrogram(nn.Module):
+    """torchaudio.transforms.Spectrogram(power=None) as the reference configures it; owns the same
+    ``window`` buffer (state_dict key ``...window``).  Framing + FFT stay on torch.stft / rocFFT."""
+
+    def __init__(self, n_fft: int, hop_length: int, normalized: bool, center: bool) -> None:
+        super().__init__()
+        self.n_fft, self.hop_length, self.normalized, self.center = n_fft, hop_length, normalized, center
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shape = x.shape
+        s = torch.stft(x.reshape(-1, shape[-1]), self.n_fft, hop_length=self.hop_length, win_length=self.n_fft,
+                       window=self.window, center=self.center, pad_mode="reflect", normalized=False, onesided=True,
+                       return_complex=True)
+        if self.normalized:   # torchaudio "window" normalisation
+            s = s / self.window.pow(2.).sum().sqrt()
+        return s.reshape(shape[:-1] + s.shape[-2:])
+
+
+def spectrogram(n_fft: int) -> Spectrogram:
+    """rave/discriminator.py:12-20."""
+    return Spectrogram(n_fft, hop_length=n_fft // 4, normalized=True, center=False)
+
+
+def rectified_2d_conv_block(capacity, kernel_sizes, strides=None, dilations=None, in_size=None, out_size=None,
+                            activation: bool = True):
+    """rave/discriminator.py:23-51 (same module tree / state_dict keys) on cc.Conv2d."""
+    if dilations is None:
+        paddings = kernel_sizes[0] // 2, kernel_sizes[1] // 2
+    else:
+        fks = (kernel_sizes[0] - 1) * dilations[0], (kernel_sizes[1] - 1) * dilations[1]
+        paddings = fks[0] // 2, fks[1] // 2
+    conv = normalization(cc.Conv2d(in_size or capacity, out_size or capacity, kernel_size=kernel_sizes,
+                                   stride=strides or (1, 1), dilation=dilations or (1, 1), padding=paddings))
+    if not activation:
+        return conv
+    return nn.Sequential(conv, nn.LeakyReLU(.2))
+
+
+def run_conv2d_layer(layer, x):
+    """conv (+ LeakyReLU fused into the conv's epilogue) of a WNConv2d / rectified block."""
+    if isinstance(layer, nn.Sequential):
+        return layer[0](x, act=ACT_LEAKY, slope=float(layer[1].negative_slope))
+    return layer(x)
+
+
+class EncodecConvNet(nn.Module):
+    """rave/discriminator.py:54-74."""
+
+    def __init__(self, capacity: int, n_channels: int = 1) -> None:
+        super().__init__()
+        self.net = nn.Sequential(
+            rectified_2d_conv_block(capacity, (9, 3), in_size=2 * n_channels),
+            rectified_2d_conv_block(capacity, (9, 3), (2, 1), (1, 1)),
+            rectified_2d_conv_block(capacity, (9, 3), (2, 1), (1, 2)),
+            rectified_2d_conv_block(capacity, (9, 3), (2, 1), (1, 4)),
+            rectified_2d_conv_block(capacity, (3, 3)),
+            rectified_2d_conv_block(capacity, (3, 3), out_size=1, activation=False),
+        )
+
+    def forward(self, x):
+        features = []
+        for layer in self.net:
+            x = run_conv2d_layer(layer, x)
+            features.append(x)
+        return features
+
+
+class MultiScaleSpectralDiscriminator(nn.Module):
+    """rave/discriminator.py:139-153."""
+
+    def __init__(self, scales: Sequence[int], convnet, n_channels: int = 1) -> None:
+        super().__init__()
+        self.specs = nn.ModuleList([spectrogram(n) for n in scales])
+        self.nets = nn.ModuleList([convnet(n_channels=n_channels) for _ in scales])
+
+    def forward(self, x):
+        features = []
+        for spec, net in zip(self.specs, self.nets):
+            spec_x = spec(x)
+            spec_x = torch.cat([spec_x.real, spec_x.imag], 1)
+            features.append(net(spec_x))
+        return features

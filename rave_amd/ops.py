@@ -334,6 +334,98 @@ def residual_unit(x, w3, w1, g3: ConvGeom, g1: ConvGeom, alpha0=None, alpha2=Non
     return _ResidualUnitFn.apply(x, w3, w3_g, w1, w1_g, alpha0, alpha2, g3, g1, pre3, pre1)
 
 
+# --------------------------------------------------------------------------- general Conv2d
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def _conv2d_cost(d: "L.Conv2dDesc"):
+    flops = 2.0 * d.batch * d.c_out * d.c_in * d.kh * d.kw * d.h_out * d.w_out
+    elems = d.batch * (d.c_in * d.h_in * d.w_in + d.c_out * d.h_out * d.w_out) + d.c_out * d.c_in * d.kh * d.kw
+    return flops, 4.0 * elems
+
+
+def _launch2(kind: str, d, fn):
+    if _PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    f, b = _conv2d_cost(d)
+    _PROFILE.append((kind, f, b, e0, e1))
+    return r
+
+
+class _Conv2dFn(torch.autograd.Function):
+    """y = act(conv2d(x, w) + bias) with zero padding (rh_conv2d_*_f32): torch.nn.Conv2d followed by the
+    LeakyReLU the reference's discriminators put after it (rave/discriminator.py:23-51,
+    rave/descript_discriminator.py:22-27)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, act: int, slope: float):
+        x = _chk(x, "x"); weight = _chk(weight, "weight"); bias = _chk(bias, "bias")
+        if x.dim() != 4 or weight.dim() != 4:
+            raise RuntimeError("rave_amd conv2d: expects x (B,C,H,W) and weight (Co,Ci,kh,kw)")
+        b, c_in, h_in, w_in = x.shape
+        c_out, c_in_w, kh, kw = weight.shape
+        if c_in != c_in_w:
+            raise RuntimeError(f"rave_amd conv2d: input has {c_in} channels, weight expects {c_in_w}")
+        (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+        h_out = (h_in + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+        w_out = (w_in + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+        d = L.Conv2dDesc(batch=b, c_in=c_in, c_out=c_out, h_in=h_in, w_in=w_in, h_out=h_out, w_out=w_out, kh=kh, kw=kw,
+                         sh=sh, sw=sw, dh=dh, dw=dw, ph=ph, pw=pw, act=act, act_slope=slope)
+        dref = C.byref(d)
+        s = L.stream()
+        dev = x.device
+        nf = L.lib.rh_conv2d_packed_floats(dref, 0)
+        if nf < 0:
+            L.check(-1, "conv2d geometry")
+        wp_f = torch.empty(nf, device=dev, dtype=torch.float32)
+        wp_b = torch.empty(L.lib.rh_conv2d_packed_floats(dref, 1), device=dev, dtype=torch.float32) \
+            if ctx.needs_input_grad[0] else None
+        L.check(L.lib.rh_conv2d_pack_f32(dref, L.ptr(weight), L.ptr(wp_f), L.ptr(wp_b), s), "conv2d_pack")
+        y = torch.empty(b, c_out, h_out, w_out, device=dev, dtype=torch.float32)
+        L.check(_launch2("conv2d_fwd", d, lambda: L.lib.rh_conv2d_fwd_f32(dref, L.ptr(x), L.ptr(wp_f), L.ptr(bias), L.ptr(y), s)),
+                "conv2d_fwd")
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, wp_b)
+        ctx.d = d
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wp_b = ctx.saved_tensors
+        d = ctx.d
+        dref = C.byref(d)
+        dy = _chk(dy, "dy")
+        s = L.stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(_launch2("conv2d_dgrad", d, lambda: L.lib.rh_conv2d_bwd_data_f32(
+                dref, L.ptr(dy), L.ptr(y), L.ptr(wp_b), L.ptr(dx), s)), "conv2d_bwd_data")
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:
+            dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
+            if need_b:
+                db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
+            nbytes = L.lib.rh_conv2d_workspace_bytes(dref)
+            ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
+            L.check(_launch2("conv2d_wgrad", d, lambda: L.lib.rh_conv2d_bwd_weight_f32(
+                dref, L.ptr(dy), L.ptr(y), L.ptr(x), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes, s)), "conv2d_bwd_weight")
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, stride=1, padding=0, dilation=1,
+           act: int = ACT_NONE, slope: float = 0.2) -> Tensor:
+    """``act(F.conv2d(x, weight, bias, stride, padding, dilation))`` on the HIP kernels (groups == 1)."""
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, dilation, act, float(slope))
+
+
 # --------------------------------------------------------------------------- PQMF
 class _PqmfAnalysisFn(torch.autograd.Function):
     @staticmethod

@@ -134,3 +134,23 @@ def test_latent_wrappers_match_reference():
     b, db = d_hip.reparametrize(z)
     assert torch.equal(a, b) and float(da) == float(db) == 0.0
     assert set(d_ref.state_dict()) == set(d_hip.state_dict())
+
+
+def test_conv2d_discriminator_mirrors_have_reference_state_dict_layout(golden_dir):
+    """Module tree / parameter names / shapes of the spectral and descript discriminator mirrors equal the
+    reference's (recorded in the golden fixture by oracle/make_golden.py); no GPU compute."""
+    import os
+    from functools import partial
+    import torch
+    from rave_amd import descript_discriminator as DD, discriminator as D
+    g = torch.load(os.path.join(golden_dir, "disc2d_tiny.pt"), weights_only=False)
+    c = g["encodec"]["config"]
+    m = D.MultiScaleSpectralDiscriminator(c["scales"], partial(D.EncodecConvNet, capacity=c["capacity"]),
+                                          n_channels=c["n_channels"])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith(".window")} == g["encodec"]["shapes"]
+    assert sum(k.endswith(".window") for k in m.state_dict()) == len(c["scales"])
+    c = g["descript"]["config"]
+    m = DD.DescriptDiscriminator(periods=c["periods"], fft_sizes=c["fft_sizes"], n_channels=c["n_channels"])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith(".window")} == g["descript"]["shapes"]
+    with __import__("pytest").raises(RuntimeError):
+        m(torch.zeros(1, 2, 2048))      # CPU tensors: the HIP path has no CPU fallback

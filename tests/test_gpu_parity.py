@@ -619,3 +619,132 @@ def test_v2_full_size_forward_vs_oracle(dev):
     assert rel_l2(zp, ref["z_params"]) < TOL_E2E
     assert rel_l2(y_mb, ref["y_mb"]) < TOL_E2E
     assert rel_l2(y_raw, ref["y_raw"]) < TOL_E2E
+
+
+# --------------------------------------------------------------------------- general Conv2d
+# (B, Ci, Co, H, W, (kh,kw), (sh,sw), (dh,dw), (ph,pw), act)
+CONV2D_CASES = [
+    (2, 2, 8, 257, 29, (9, 3), (1, 1), (1, 1), (4, 1), 1),      # Encodec block 0 (rave/discriminator.py:60)
+    (2, 8, 8, 257, 29, (9, 3), (2, 1), (1, 1), (4, 1), 1),      # block 1
+    (2, 8, 8, 129, 29, (9, 3), (2, 1), (1, 2), (4, 2), 1),      # block 2: dilation 2 along W
+    (2, 8, 8, 65, 29, (9, 3), (2, 1), (1, 4), (4, 4), 1),       # block 3: dilation 4 along W
+    (2, 8, 1, 33, 29, (3, 3), (1, 1), (1, 1), (1, 1), 0),       # last block, M = 1
+    (1, 32, 32, 33, 129, (3, 9), (1, 2), (1, 1), (1, 4), 1),    # descript MRD (descript_discriminator.py:137)
+    (1, 4, 32, 33, 257, (3, 9), (1, 1), (1, 1), (1, 4), 1),     # MRD first conv, stereo
+    (2, 32, 128, 228, 3, (5, 1), (3, 1), (1, 1), (2, 0), 1),    # descript MPD (5,1) stride (3,1)
+    (1, 128, 160, 40, 5, (5, 1), (1, 1), (1, 1), (2, 0), 1),    # M > 128 -> 128-row tiles
+    (3, 96, 96, 20, 20, (3, 3), (1, 1), (1, 1), (1, 1), 1),     # 96-row tiles
+    (5, 3, 5, 7, 6, (3, 2), (2, 2), (1, 1), (1, 1), 0),         # tiny planes: batch folding, stride in both dims
+    (2, 6, 7, 19, 23, (4, 3), (3, 2), (2, 2), (3, 2), 1),       # stride + dilation in both dims, even kernel
+    (1, 5, 4, 9, 1, (3, 1), (1, 1), (1, 1), (1, 0), 0),         # W = 1
+    (2, 4, 4, 16, 300, (1, 1), (1, 1), (1, 1), (0, 0), 1),      # 1x1, wide rows
+    (1, 3, 4, 11, 13, (2, 2), (4, 1), (1, 1), (0, 0), 1),       # stride > kernel: data-gradient phases without taps
+]
+
+
+@pytest.mark.parametrize("case", CONV2D_CASES)
+def test_conv2d_fwd_and_grads_vs_cpu(dev, ops, case):
+    B, Ci, Co, H, W, k, s, d, p, act = case
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, *k, generator=g) / math.sqrt(Ci * k[0] * k[1])
+    b = torch.randn(Co, generator=g) * 0.1
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv2d(xd, wd, bd, s, p, d)
+    if act:
+        ref = F.leaky_relu(ref, 0.1)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xg, wg, bg, s, p, d, act=ops.ACT_LEAKY if act else ops.ACT_NONE, slope=0.1)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < TOL_OP
+    y.backward(cot.to(dev))
+    assert rel_l2(xg.grad, xd.grad) < TOL_OP
+    assert rel_l2(wg.grad, wd.grad) < TOL_OP
+    assert rel_l2(bg.grad, bd.grad) < TOL_OP
+    # determinism of the split-K weight gradient
+    xg2, wg2 = xg.detach().clone().requires_grad_(True), wg.detach().clone().requires_grad_(True)
+    ops.conv2d(xg2, wg2, None, s, p, d, act=ops.ACT_LEAKY if act else ops.ACT_NONE, slope=0.1).backward(cot.to(dev))
+    xg3, wg3 = xg.detach().clone().requires_grad_(True), wg.detach().clone().requires_grad_(True)
+    ops.conv2d(xg3, wg3, None, s, p, d, act=ops.ACT_LEAKY if act else ops.ACT_NONE, slope=0.1).backward(cot.to(dev))
+    assert torch.equal(wg2.grad, wg3.grad) and torch.equal(xg2.grad, xg3.grad)
+
+
+def test_conv2d_no_bias_and_empty_batch(dev, ops):
+    w = torch.randn(4, 3, 3, 3).to(dev)
+    y = ops.conv2d(torch.zeros(0, 3, 8, 8, device=dev), w, None, 1, 1, 1)
+    assert y.shape == (0, 4, 8, 8)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 2, 8, 8, device=dev), w, None, 1, 1, 1)     # channel mismatch
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 3, 2, 2, device=dev), w, None, 1, 0, 1)     # kernel larger than the input
+
+
+def _check_disc_golden(g, model, dev, feats_of):
+    sd = g.get("state_dict") or O.seeded_state_dict(g["shapes"], g["seed"])
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith(".window") for k in res.missing_keys)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith(".window")} == g["shapes"]
+    model.to(dev)
+    x = g["x"].to(dev).requires_grad_(True)
+    feats = feats_of(model, x)
+    assert [len(n) for n in feats] == [len(n) for n in g["features"]]
+    worst = 0.0
+    for net, gnet in zip(feats, g["features"]):
+        for f, gf in zip(net, gnet):
+            assert f.shape == gf.shape
+            worst = max(worst, rel_l2(f, gf))
+    assert worst < TOL_E2E, worst
+    loss = sum(f.pow(2).mean() for net in feats for f in net)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    assert rel_l2(x.grad, g["dx"]) < TOL_E2E
+    step = g["grad_step"]
+    for k, p in model.named_parameters():
+        got = p.grad.reshape(-1)
+        got = got if got.numel() <= 200_000 else got[::step]
+        assert rel_l2(got, g["grads"][k]) < TOL_E2E, k
+
+
+def test_encodec_spectral_discriminator_golden(golden_dir, dev):
+    """rave/discriminator.py:54-74,139-153 (spectral_discriminator.gin) vs the reference's own output."""
+    from functools import partial
+    from rave_amd import discriminator as D
+    g = _load(golden_dir, "disc2d_tiny.pt")["encodec"]
+    c = g["config"]
+    model = D.MultiScaleSpectralDiscriminator(c["scales"], partial(D.EncodecConvNet, capacity=c["capacity"]),
+                                              n_channels=c["n_channels"])
+    _check_disc_golden(g, model, dev, lambda m, x: m(x))
+
+
+def test_descript_discriminator_golden(golden_dir, dev):
+    """rave/descript_discriminator.py:187-217 (v3.gin; stereo) vs the reference's own output."""
+    from rave_amd import descript_discriminator as DD
+    g = _load(golden_dir, "disc2d_tiny.pt")["descript"]
+    c = g["config"]
+    model = DD.DescriptDiscriminator(periods=c["periods"], fft_sizes=c["fft_sizes"], n_channels=c["n_channels"])
+    _check_disc_golden(g, model, dev, lambda m, x: m(x))
+
+
+def test_descript_discriminator_v3_shapes_vs_oracle(dev):
+    """v3 stereo configuration (periods 2,3,5,7,11 and fft 2048/1024/512) on a 16384-sample clip: every
+    feature map against the CPU oracle restatement with seeded weights."""
+    from rave_amd import descript_discriminator as DD
+    periods, ffts = [2, 3, 5, 7, 11], [2048, 1024, 512]
+    model = DD.DescriptDiscriminator(periods=periods, fft_sizes=ffts, n_channels=2)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith(".window")}
+    sd = O.seeded_state_dict(shapes, 7)
+    model.load_state_dict(sd, strict=False)
+    model.to(dev)
+    x = O.synthetic_batch(1, 2, 16384, seed=5)
+    with torch.no_grad():
+        got = model(x.to(dev))
+        ref = O.descript_discriminator(x, {"d." + k: v for k, v in sd.items()}, "d", periods, ffts)
+    worst = 0.0
+    for net, rnet in zip(got, ref):
+        assert len(net) == len(rnet)
+        for f, rf in zip(net, rnet):
+            assert f.shape == rf.shape
+            worst = max(worst, rel_l2(f, rf))
+    assert worst < TOL_E2E, worst
