@@ -77,6 +77,10 @@ typedef struct rh_conv1d_desc {
     int32_t in_valid; /* 0 = l_in*inner */
     int32_t act;      /* enum rh_act, fused on the conv input */
     float act_slope;  /* LeakyReLU slope */
+    int32_t out_act;  /* RH_ACT_NONE / RH_ACT_LEAKY applied to the OUTPUT (forward only): y = out_act(conv + bias
+                       * + residual), as WNConv2d(...) + LeakyReLU(0.1) of rave/descript_discriminator.py:22-27.
+                       * The backward entry points ignore it: pass dy * out_act'(y) (rh_act_bwd_f32). */
+    float out_slope;
 } rh_conv1d_desc;
 
 int rh_version(void);
@@ -188,6 +192,9 @@ int64_t rh_snake_bwd_workspace_bytes(int32_t batch, int32_t c);
 int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_t batch, int32_t c,
                      int32_t l, float* dx, float* dalpha, void* workspace, int64_t workspace_bytes,
                      rh_stream_t stream);
+/* g = dy * act'(y) for an OUTPUT LeakyReLU (sign(y) == sign(pre-activation)): the cotangent the backward
+ * entry points of a conv with out_act expect. */
+int rh_act_bwd_f32(const float* dy, const float* y, int32_t act, float slope, int64_t n, float* g, rh_stream_t stream);
 /* nn.functional.avg_pool1d(x, 2) of MultiScaleDiscriminator (rave/discriminator.py:135). */
 int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
 int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);

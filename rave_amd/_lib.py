@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
         ("stride", C.c_int32), ("dilation", C.c_int32), ("pad_left", C.c_int32),
         ("transposed", C.c_int32), ("groups", C.c_int32), ("inner", C.c_int32),
         ("in_valid", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+        ("out_act", C.c_int32), ("out_slope", C.c_float),
     ]
 
 
@@ -74,6 +75,7 @@ def _load() -> C.CDLL:
         "rh_amp_tanh_fwd_f32": ([P, I32, I32, I32, P, P], C.c_int),
         "rh_amp_tanh_bwd_f32": ([P, P, I32, I32, I32, P, P], C.c_int),
         "rh_act_fwd_f32": ([P, P, I32, F, I32, I32, I32, P, P], C.c_int),
+        "rh_act_bwd_f32": ([P, P, I32, F, I64, P, P], C.c_int),
         "rh_snake_bwd_workspace_bytes": ([I32, I32], I64),
         "rh_snake_bwd_f32": ([P, P, P, I32, I32, I32, P, P, P, I64, P], C.c_int),
         "rh_stft_frame_fwd_f32": ([P, P, I64, I32, I32, I32, I32, P, P], C.c_int),

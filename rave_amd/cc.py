@@ -187,6 +187,14 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError("rave_amd.cc.Conv2d: groups / padding_mode")
 
     def forward(self, x, act: int = ACT_NONE, slope: float = 0.2):
+        if (self.kernel_size[1] == 1 and self.stride[1] == 1 and self.padding[1] == 0 and self.dilation == (1, 1)
+                and self.stride[0] <= 8):
+            # (k,1) kernels (descript MPD: up to 1024 channels on a period-wide plane): the 1-D LDS-DMA
+            # kernels with W as contiguous "inner" columns are ~4x faster than the general 2-D tiling there
+            g = ConvGeom(stride=self.stride[0], dilation=1, pad_left=self.padding[0], pad_right=self.padding[0],
+                         inner=x.shape[3], out_act=act, out_slope=slope)
+            w, wg = _wn_pair(self)
+            return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg)
         return ops.conv2d(x, _effective_weight(self), self.bias, self.stride, self.padding, self.dilation, act, slope)
 
 

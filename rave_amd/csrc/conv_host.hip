@@ -28,6 +28,8 @@ int validate(const rh_conv1d_desc* d) {
     RH_REQUIRE(d->groups == 1, RH_ERR_UNSUPPORTED, "conv1d: groups = %d not implemented", d->groups);
     RH_REQUIRE(d->kernel <= kMaxTaps, RH_ERR_UNSUPPORTED, "conv1d: kernel %d > %d", d->kernel, kMaxTaps);
     RH_REQUIRE(d->act >= RH_ACT_NONE && d->act <= RH_ACT_SNAKE, RH_ERR_INVALID, "conv1d: bad act");
+    RH_REQUIRE(d->out_act == RH_ACT_NONE || d->out_act == RH_ACT_LEAKY, RH_ERR_UNSUPPORTED,
+               "conv1d: out_act must be none or leaky");
     RH_REQUIRE(d->in_valid >= 0 && d->in_valid <= (int64_t)d->l_in * d->inner, RH_ERR_INVALID,
                "conv1d: in_valid out of range");
     if (d->transposed) {
@@ -212,6 +214,8 @@ int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p) {
     p->in_slope = d->act_slope;
     p->epi_act = RH_ACT_NONE;
     p->epi_slope = 0.f;
+    p->out_act = d->out_act;
+    p->out_slope = d->out_slope;
     return RH_OK;
 }
 
@@ -232,6 +236,8 @@ int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p) {
     p->in_slope = 0.f;
     p->epi_act = d->act;
     p->epi_slope = d->act_slope;
+    p->out_act = RH_ACT_NONE;      // the caller pre-multiplies dy by out_act'(y) (rh_act_bwd_f32)
+    p->out_slope = 0.f;
     return RH_OK;
 }
 

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
                         v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
                     }
                     if (p.add) v += p.add[idx];
+                    if (p.out_act == RH_ACT_LEAKY) v = v > 0.f ? v : v * p.out_slope;
                     p.out[idx] = v;
                 }
             }

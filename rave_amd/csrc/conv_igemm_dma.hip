@@ -312,6 +312,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
                         v *= rh_act_grad(mulp[ro], p.epi_act, p.epi_slope, al);
                     }
                     if (addp) v += addp[ro];
+                    if (p.out_act == RH_ACT_LEAKY) v = v > 0.f ? v : v * p.out_slope;
                     outp[ro] = v;
                 }
             }
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvP p, lon
         v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
     }
     if (p.add) v += p.add[idx];
+    if (p.out_act == RH_ACT_LEAKY) v = v > 0.f ? v : v * p.out_slope;
     p.out[idx] = v;
 }
 

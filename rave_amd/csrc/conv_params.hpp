@@ -27,8 +27,8 @@ struct ConvP {
     int pitch;                                 // LDS pitch of one staged input row
     int ck;                                    // channels per K chunk (even)
     int wlds_floats;                           // floats reserved for the weight tile in LDS
-    int in_act, epi_act;
-    float in_slope, epi_slope;
+    int in_act, epi_act, out_act;              // out_act: LeakyReLU on the OUTPUT (after bias / add)
+    float in_slope, epi_slope, out_slope;
     // --- LDS-DMA (async global->LDS) pipeline only ---
     int segs;                                  // 64-float segments per staged input row (pitch = 64*segs)
     unsigned magic_segs, magic_ck, magic_lpr;  // ceil(2^20 / d): exact n/d for n*d < 2^20

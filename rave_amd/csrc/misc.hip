@@ -94,6 +94,23 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
     y[e] = rh_act_apply(x[e], act, slope, al);
 }
 
+// g = dy * act'(y) for an output LeakyReLU, 4 elements per lane where alignment allows
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act,
+                                                      float slope, long n4, long total, float* __restrict__ g) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n4) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(dy)[e];
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[e];
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = d[i] * rh_act_grad(v[i], act, slope, 0.f);
+        reinterpret_cast<f32x4*>(g)[e] = o;
+    } else {
+        const long t = n4 * 4 + (e - n4);
+        if (t < total) g[t] = dy[t] * rh_act_grad(y[t], act, slope, 0.f);
+    }
+}
+
 // Snake backward (rave/blocks.py:852-860): f = x + sin^2(a x)/(a+eps)
 //   df/dx = 1 + a sin(2 a x)/(a+eps) ;  df/da = x sin(2 a x)/(a+eps) - sin^2(a x)/(a+eps)^2
 // grid (C, S): block (c, s) handles batch items s, s+S, ... of channel c; writes dx and a partial
@@ -264,6 +281,20 @@ extern "C" int rh_act_fwd_f32(const float* x, const float* snake_alpha, int32_t 
     hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, snake_alpha, act,
                        slope, c, (long)l, total, y);
     return rh_check_launch("act_fwd");
+}
+
+extern "C" int rh_act_bwd_f32(const float* dy, const float* y, int32_t act, float slope, int64_t n, float* g,
+                              rh_stream_t stream) {
+    RH_REQUIRE(n >= 0, RH_ERR_INVALID, "act_bwd: bad size");
+    if (n == 0) return RH_OK;
+    RH_REQUIRE(dy && y && g, RH_ERR_INVALID, "act_bwd: null pointer");
+    RH_REQUIRE(act == RH_ACT_NONE || act == RH_ACT_LEAKY, RH_ERR_UNSUPPORTED, "act_bwd: none / leaky only");
+    const bool al = (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g) & 15) == 0;
+    const long n4 = al ? n / 4 : 0;
+    const long threads = n4 + (n - 4 * n4);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(threads)), dim3(256), 0, (hipStream_t)stream, dy, y, act, slope,
+                       n4, (long)n, g);
+    return rh_check_launch("act_bwd");
 }
 
 extern "C" int64_t rh_snake_bwd_workspace_bytes(int32_t batch, int32_t c) {

@@ -80,6 +80,8 @@ class ConvGeom:
     slope: float = 0.2
     inner: int = 1          # W of a Conv2d with (k,1) kernel on (B,C,H,W)
     fold: bool = False      # input is the un-folded (B,C,T) waveform of MultiPeriodDiscriminator
+    out_act: int = ACT_NONE  # LeakyReLU on the OUTPUT (descript WNConv2d + LeakyReLU(0.1))
+    out_slope: float = 0.1
 
     def out_len(self, l_in: int, k: int) -> int:
         if self.transposed:
@@ -91,7 +93,7 @@ def _desc(g: ConvGeom, batch, c_in, c_out, l_in, l_out, k, in_valid=0) -> L.Conv
     return L.ConvDesc(batch=batch, c_in=c_in, c_out=c_out, l_in=l_in, l_out=l_out, kernel=k,
                       stride=g.stride, dilation=g.dilation, pad_left=g.pad_left,
                       transposed=int(g.transposed), groups=1, inner=g.inner, in_valid=in_valid,
-                      act=g.act, act_slope=g.slope)
+                      act=g.act, act_slope=g.slope, out_act=g.out_act, out_slope=g.out_slope)
 
 
 def _ws(nbytes: int, device) -> Optional[Tensor]:
@@ -190,7 +192,8 @@ class _ConvFn(torch.autograd.Function):
         if residual is not None and residual.shape != y.shape:
             raise RuntimeError(f"rave_amd conv: residual shape {tuple(residual.shape)} != output {tuple(y.shape)}")
         L.check(_fwd(d, x, wp_f, bias, alpha, residual, y, s), "conv1d_fwd")
-        ctx.save_for_backward(x, wp_b, alpha, weight if g is not None else None, g, norms)
+        ctx.save_for_backward(x, wp_b, alpha, weight if g is not None else None, g, norms,
+                              y if geom.out_act != ACT_NONE else None)
         ctx.d = d
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -199,12 +202,17 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, wp_b, alpha, v, g, norms = ctx.saved_tensors
+        x, wp_b, alpha, v, g, norms, y_act = ctx.saved_tensors
         d = ctx.d
         dref = C.byref(d)
         dy = _chk(dy, "dy")
         s = L.stream()
         dx = dw = dg = db = dres = None
+        if y_act is not None:      # output activation: every gradient below is taken w.r.t. the pre-activation
+            gpre = torch.empty_like(dy)
+            L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y_act), d.out_act, d.out_slope, dy.numel(), L.ptr(gpre), s),
+                    "act_bwd")
+            dy = gpre
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(_dgrad(d, dy, wp_b, x, alpha, None, dx, s), "conv1d_bwd_data")

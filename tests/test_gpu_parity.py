@@ -748,3 +748,25 @@ def test_descript_discriminator_v3_shapes_vs_oracle(dev):
             assert f.shape == rf.shape
             worst = max(worst, rel_l2(f, rf))
     assert worst < TOL_E2E, worst
+
+
+@pytest.mark.parametrize("W,Ci,Co,H,k,s", [(3, 32, 128, 228, 5, 3), (2, 1024, 1, 41, 3, 1), (11, 128, 96, 70, 5, 1)])
+def test_conv_k1_with_output_leaky_vs_cpu(dev, ops, W, Ci, Co, H, k, s):
+    """(k,1) Conv2d + LeakyReLU(0.1) on the OUTPUT through the 1-D LDS-DMA kernels (descript MPD,
+    rave/descript_discriminator.py:36-48): y = leaky(conv + b); backward through rh_act_bwd_f32."""
+    g = torch.Generator().manual_seed(W * 100 + Ci)
+    x = torch.randn(2, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, 1, generator=g) / math.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g) * 0.1
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.leaky_relu(F.conv2d(xd, wd, bd, (s, 1), (k // 2, 0)), 0.1)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    geom = ops.ConvGeom(stride=s, pad_left=k // 2, pad_right=k // 2, inner=W, out_act=ops.ACT_LEAKY, out_slope=0.1)
+    y = ops.conv1d(xg, wg, bg, geom=geom)
+    assert y.shape == ref.shape and rel_l2(y, ref) < TOL_OP
+    y.backward(cot.to(dev))
+    assert rel_l2(xg.grad, xd.grad) < TOL_OP
+    assert rel_l2(wg.grad, wd.grad) < TOL_OP
+    assert rel_l2(bg.grad, bd.grad) < TOL_OP
