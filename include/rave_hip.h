@@ -243,6 +243,23 @@ int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d);
 int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x, float* dw,
                              float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream);
 
+/* ---- residual vector quantisation ------------------------------- */
+
+/* One EuclideanCodebook step (rave/quantization.py:131-181) on n_vectors x dim row-major vectors:
+ * indices[n] = argmin_k (|x_n|^2 - 2 x_n.e_k) + |e_k|^2 (first index on ties, as torch.max of the negated
+ * distance); residual[n] = x_n - e_ind (input of the next quantiser, ResidualVectorQuantization.forward
+ * :283-300; may alias x; may be null); quantized_sum[n] += e_ind (may be null);
+ * loss_partials[rh_vq_loss_partials(n_vectors)] = per-block sums of |e_ind - x_n|^2 (commitment loss
+ * numerator, :263-266; may be null). */
+int64_t rh_vq_loss_partials(int64_t n_vectors);
+int rh_vq_assign_f32(const float* x, const float* embed, int64_t n_vectors, int32_t dim, int32_t codebook_size,
+                     int64_t* indices, float* residual, float* quantized_sum, float* loss_partials, rh_stream_t stream);
+/* Training-time codebook update (:165-179): cluster_size / embed_avg EMAs from per-code counts and ordered
+ * vector sums (deterministic), then embed = embed_avg / (laplace_smoothing(cluster_size) * sum). */
+int rh_vq_ema_update_f32(const float* x, const int64_t* indices, int64_t n_vectors, int32_t dim, int32_t codebook_size,
+                         float decay, float epsilon, float* cluster_size, float* embed_avg, float* embed,
+                         rh_stream_t stream);
+
 /* ---- spectral distance ("next" item #1 of SURVEY.md section 8f, beside the hot path) ------------- */
 
 /* STFT framing of torchaudio.transforms.Spectrogram(center=True, pad_mode="reflect") as used by

@@ -311,6 +311,38 @@ def golden_disc2d(name="disc2d_tiny.pt"):
     print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
 
 
+def golden_rvq(name="rvq_tiny.pt"):
+    """rave.quantization.ResidualVectorQuantization (discrete.gin:37-40 shrunk): k-means initialisation on a
+    first batch (reference code, CPU RNG), then ONE training forward/backward and one eval forward on a second
+    batch: outputs, commitment loss, indices, dL/dz and the EMA-updated codebook buffers."""
+    from ref_import import import_reference
+    import_reference()
+    from rave import quantization as rq
+    out = {}
+    for tag, (nq, dim, k, b, tl) in dict(small=(4, 16, 32, 3, 40), wide=(3, 64, 256, 4, 128)).items():
+        torch.manual_seed(5)
+        m = rq.ResidualVectorQuantization(num_quantizers=nq, dim=dim, codebook_size=k)
+        m.train()
+        gen = torch.Generator().manual_seed(17)
+        with torch.no_grad():
+            m(torch.randn(b, dim, tl, generator=gen))         # k-means init + first EMA step
+        sd0 = {kk: t(v) for kk, v in m.state_dict().items()}
+        z = torch.randn(b, dim, tl, generator=gen).requires_grad_(True)
+        q, loss, ind = m(z)
+        cot = torch.randn(q.shape, generator=gen)
+        ((q * cot).sum() + 3.0 * loss).backward()
+        sd1 = {kk: t(v) for kk, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            q_eval, loss_eval, ind_eval = m(z.detach())
+        out[tag] = dict(config=dict(num_quantizers=nq, dim=dim, codebook_size=k), sd0=sd0, z=t(z), cot=cot,
+                        q=t(q), loss=t(loss), ind=t(ind), dz=t(z.grad), sd1=sd1, q_eval=t(q_eval),
+                        loss_eval=t(loss_eval), ind_eval=t(ind_eval))
+        print(tag, "loss", float(loss.detach()), "codes used", int(ind.unique().numel()))
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
@@ -320,3 +352,4 @@ if __name__ == "__main__":
     golden_v2_small_tiny()
     golden_v1_tiny()
     golden_disc2d()
+    golden_rvq()

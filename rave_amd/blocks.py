@@ -450,10 +450,11 @@ class SphericalEncoder(nn.Module):
 
 
 class DiscreteEncoder(nn.Module):
-    """rave/blocks.py:794-830 (configs/discrete.gin) with the quantiser DISABLED, which is the state
-    the shipped trainer always leaves it in (QuantizeCallback.on_train_batch_ is never called by
-    Lightning -- SURVEY.md Appendix B #10): pass-through + ``noise_augmentation`` extra noise channels.
-    The residual vector quantiser itself (rave/quantization.py) is out of the hot-path scope."""
+    """rave/blocks.py:794-830 (configs/discrete.gin).  ``enabled`` == 0 (the state the shipped trainer
+    always leaves it in: QuantizeCallback.on_train_batch_ is never called by Lightning -- SURVEY.md
+    Appendix B #10): pass-through + ``noise_augmentation`` extra noise channels.  ``enabled`` != 0: the
+    residual vector quantiser ``vq_cls`` (rave_amd.quantization.ResidualVectorQuantization on the HIP VQ
+    kernels) replaces z by its quantisation and returns the commitment loss."""
 
     def __init__(self, encoder_cls, vq_cls=None, num_quantizers: int = 16, noise_augmentation: int = 0,
                  n_channels: int = 1):
@@ -468,7 +469,7 @@ class DiscreteEncoder(nn.Module):
     def reparametrize(self, z, eps=None, noise: Optional[torch.Tensor] = None):
         if self.enabled:
             if self.rvq is None:
-                raise NotImplementedError("rave_amd DiscreteEncoder: RVQ (rave/quantization.py) is out of scope")
+                raise RuntimeError("rave_amd DiscreteEncoder: enabled but constructed without vq_cls")
             z, diff, _ = self.rvq(z)
         else:
             diff = torch.zeros_like(z).mean()

@@ -770,3 +770,50 @@ def test_conv_k1_with_output_leaky_vs_cpu(dev, ops, W, Ci, Co, H, k, s):
     assert rel_l2(xg.grad, xd.grad) < TOL_OP
     assert rel_l2(wg.grad, wd.grad) < TOL_OP
     assert rel_l2(bg.grad, bd.grad) < TOL_OP
+
+
+# --------------------------------------------------------------------------- RVQ
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_rvq_golden(golden_dir, dev, tag):
+    """rave/quantization.py ResidualVectorQuantization: one training step (indices bit-exact, outputs, commit
+    loss, straight-through gradient, EMA-updated codebooks) and an eval forward vs the reference's own run."""
+    from rave_amd import quantization as Q
+    g = _load(golden_dir, "rvq_tiny.pt")[tag]
+    c = g["config"]
+    m = Q.ResidualVectorQuantization(c["num_quantizers"], dim=c["dim"], codebook_size=c["codebook_size"])
+    assert set(m.state_dict().keys()) == set(g["sd0"].keys())
+    m.load_state_dict(g["sd0"])
+    m.to(dev).train()
+    z = g["z"].to(dev).requires_grad_(True)
+    q, loss, ind = m(z)
+    assert ind.shape == g["ind"].shape and torch.equal(ind.cpu(), g["ind"])
+    assert rel_l2(q, g["q"]) < TOL_OP
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    ((q * g["cot"].to(dev)).sum() + 3.0 * loss).backward()
+    assert rel_l2(z.grad, g["dz"]) < TOL_OP
+    for k, v in m.state_dict().items():
+        assert rel_l2(v, g["sd1"][k]) < TOL_OP, k
+    m.eval()
+    with torch.no_grad():
+        qe, le, ie = m(z.detach())
+    assert torch.equal(ie.cpu(), g["ind_eval"]) and rel_l2(qe, g["q_eval"]) < TOL_OP and float(le) == 0.0
+    assert torch.equal(m.encode(z.detach()).cpu(), g["ind_eval"])
+    assert rel_l2(m.decode(ie), g["q_eval"]) < TOL_OP
+
+
+def test_rvq_kmeans_init_and_discrete_encoder(dev):
+    """k-means initialisation on the first enabled call (HIP assign kernel + index_add) and the DiscreteEncoder
+    reparametrize path (rave/blocks.py:810-822): quantised latent + noise channels, finite loss, codebooks used."""
+    from rave_amd import quantization as Q
+    torch.manual_seed(0)
+    m = Q.ResidualVectorQuantization(2, dim=8, codebook_size=16, kmeans_iters=5).to(dev).train()
+    z = torch.randn(4, 8, 64, device=dev)
+    q, loss, ind = m(z)
+    assert all(bool(l._codebook.inited) for l in m.layers)
+    assert q.shape == z.shape and ind.shape == (4, 2, 64) and math.isfinite(float(loss))
+    # quantising reduces the error monotonically over the residual chain
+    with torch.no_grad():
+        m.eval()
+        q1 = m.layers[0](z)[0]
+        q2 = m(z)[0]
+    assert float((z - q2).pow(2).mean()) < float((z - q1).pow(2).mean()) < float(z.pow(2).mean())

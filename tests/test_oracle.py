@@ -322,3 +322,22 @@ def test_oracle_descript_discriminator_matches_reference_golden(golden_dir):
     sd = {"d." + k: v for k, v in O.seeded_state_dict(g["shapes"], g["seed"]).items()}
     c = g["config"]
     _oracle_disc_check(g, lambda x, p: O.descript_discriminator(x, p, "d", c["periods"], c["fft_sizes"]), sd)
+
+
+# --------------------------------------------------------------------------- RVQ
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_oracle_rvq_matches_reference_golden(golden_dir, tag):
+    g = torch.load(os.path.join(golden_dir, "rvq_tiny.pt"), weights_only=False)[tag]
+    c = g["config"]
+    sd = {"r." + k: v for k, v in g["sd0"].items()}
+    z = g["z"].clone().requires_grad_(True)
+    q, loss, ind, new = O.rvq_forward(z, sd, "r", c["num_quantizers"], training=True)
+    assert torch.equal(ind, g["ind"])                       # index work: exact
+    assert rel_l2(q, g["q"]) < 1e-6 and abs(float(loss.detach()) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    ((q * g["cot"]).sum() + 3.0 * loss).backward()
+    assert rel_l2(z.grad, g["dz"]) < 1e-6
+    for k, v in new.items():
+        assert rel_l2(v, g["sd1"][k[2:]]) < 1e-6, k
+    sd1 = {"r." + k: v for k, v in g["sd1"].items()}
+    qe, le, ie, _ = O.rvq_forward(g["z"], sd1, "r", c["num_quantizers"], training=False)
+    assert torch.equal(ie, g["ind_eval"]) and rel_l2(qe, g["q_eval"]) < 1e-6 and float(le) == 0.0
