@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--n-signal", type=int, default=65536)
     ap.add_argument("--phase", choices=["vae", "gan"], default="vae")
+    ap.add_argument("--config", choices=["v2", "discrete", "v3"], default="v2",
+                    help="v2 = BASELINE configs[1]/[2] (the metric's config); discrete = configs[3] (RVQ + spectral "
+                         "discriminator); v3 = configs[4] (stereo, causal, snake, descript discriminator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -113,7 +116,19 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
     torch.manual_seed(0)
-    m = M.build_v2().to(dev).train()
+    n_ch = 1
+    if args.config == "v2":
+        m = M.build_v2()
+    elif args.config == "discrete":
+        m = M.build_discrete()
+    else:
+        m = M.build_v3()
+        n_ch = 2
+    m = m.to(dev).train()
+    if args.config == "discrete":
+        # QuantizeCallback never fires in the shipped trainer: enable the RVQ
+        # explicitly so that rave/quantization.py is exercised; the k-means init runs in the warm-up steps
+        m.encoder.enabled.fill_(1)
     ddp.broadcast_module(m)
     gen_opt, dis_opt = m.configure_optimizers()
     m.warmed_up = args.phase == "gan"
@@ -125,9 +140,9 @@ def main():
     # synthetic 44.1 kHz waveforms, one shard per rank, resident in HBM
     g = torch.Generator().manual_seed(20250509 + rank)
     t = torch.arange(args.n_signal, dtype=torch.float32) / 44100.0
-    x = 0.1 * torch.randn(args.batch, 1, args.n_signal, generator=g)
+    x = 0.1 * torch.randn(args.batch, n_ch, args.n_signal, generator=g)
     for f0, a in ((220.0, 0.2), (1760.0, 0.1), (7040.0, 0.05)):
-        ph = torch.rand(args.batch, 1, 1, generator=g) * 6.283185307
+        ph = torch.rand(args.batch, n_ch, 1, generator=g) * 6.283185307
         x = x + a * torch.sin(6.283185307 * f0 * t + ph)
     x = x.clamp(-1, 1).to(dev)
 
@@ -161,17 +176,18 @@ def main():
     samples = world * args.batch * args.n_signal * args.steps
 
     out = {
-        "metric": "audio samples/sec/GPU (RAVE v2 training step, 44.1 kHz, n_signal=65536)",
+        "metric": f"audio samples/sec/GPU (RAVE {args.config} training step, 44.1 kHz, n_signal=65536)",
         "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"v2 config, batch {args.batch} mono 44.1 kHz n_signal={args.n_signal}, "
+        "config": {"workload": f"{args.config} config, batch {args.batch} {'stereo' if n_ch == 2 else 'mono'} 44.1 kHz "
+                               f"n_signal={args.n_signal}, "
                                f"{'VAE' if args.phase == 'vae' else 'VAE+GAN'}-phase training step per GPU",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "per_gpu_samples_per_s": samples / dt / world,
     }
 
-    if rank == 0 and not args.no_kernel_timing:
+    if rank == 0 and not args.no_kernel_timing and args.config == "v2":
         # ---- per-launch HIP-event timing of the conv kernels over instrumented replays of the step
         reps = 2
         ops.profile_begin()
@@ -238,7 +254,7 @@ def main():
                                "hbm_roofline_frac": fb / t_fwd / HBM_PEAK,
                                "f32_mfma_frac": ff / t_fwd / F32_MFMA_PEAK,
                                "samples_per_s": args.batch * args.n_signal / t_fwd}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "v2":
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
     if use_ddp:
         out["ddp"] = {"allreduce_bytes_per_step": (red_gen.bytes_reduced + (red_dis.bytes_reduced if red_dis else 0))

@@ -14,7 +14,7 @@ from typing import Callable, Dict, Optional
 import torch
 import torch.nn as nn
 
-from . import blocks, cc, discriminator, losses, pqmf
+from . import blocks, cc, descript_discriminator, discriminator, losses, pqmf, quantization
 
 _default_loss_weights = {
     "audio_distance": 1.,
@@ -251,11 +251,16 @@ def build_v2_small(**kw) -> "RAVE":
 def build_v2(n_channels: int = 1, capacity: int = 96, ratios=(4, 4, 4, 2), latent_size: int = 128,
              n_band: int = 16, dilations=None, sampling_rate: int = 44100, causal: bool = False,
              disc_capacity: Optional[int] = None, snake: bool = False, adain: bool = False,
-             noise: bool = False, update_discriminator_every: int = 4) -> RAVE:
+             noise: bool = False, update_discriminator_every: int = 4, discriminator_kind: str = "v2",
+             encoder_kind: str = "variational", noise_augmentation: int = 0, num_quantizers: int = 16,
+             codebook_size: int = 1024, log_epsilon: float = 1e-7, num_skipped_features: int = 1,
+             spectral_capacity: int = 32) -> RAVE:
     """configs/v1.gin + configs/v2.gin transcribed (cf. oracle/ref_models.py for the citations).
     ``snake`` / ``adain`` add the generator-side overlays of configs/v3.gin (snake.gin: every activation
     -> blocks.Snake; adain.gin: AdaptiveInstanceNormalization before every unit); ``causal`` =
-    configs/causal.gin."""
+    configs/causal.gin.  ``discriminator_kind``: "v2" (MPD + MSD, v2.gin:53-75), "descript"
+    (descript_discriminator.gin), "spectral" (spectral_discriminator.gin: MSD + Encodec STFT nets).
+    ``encoder_kind``: "variational" or "discrete" (discrete.gin: EncoderV2(n_out=1) + RVQ + noise channels)."""
     cc.set_default_padding_mode("causal" if causal else "centered")
     blocks.set_normalization_mode("weight_norm")
     dil = dilations or V2_DILATIONS
@@ -266,34 +271,71 @@ def build_v2(n_channels: int = 1, capacity: int = 96, ratios=(4, 4, 4, 2), laten
         extra["activation"] = blocks.Snake
     if adain:
         extra["adain"] = blocks.AdaptiveInstanceNormalization
-    enc = partial(blocks.VariationalEncoder,
-                  encoder=partial(blocks.EncoderV2, data_size=n_band, capacity=capacity, ratios=ratios,
-                                  latent_size=latent_size, n_out=2, kernel_size=3, dilations=dil, **extra))
+    if encoder_kind == "variational":
+        enc = partial(blocks.VariationalEncoder,
+                      encoder=partial(blocks.EncoderV2, data_size=n_band, capacity=capacity, ratios=ratios,
+                                      latent_size=latent_size, n_out=2, kernel_size=3, dilations=dil, **extra))
+    elif encoder_kind == "discrete":   # configs/discrete.gin:24-40
+        enc = partial(blocks.DiscreteEncoder,
+                      encoder_cls=partial(blocks.EncoderV2, data_size=n_band, capacity=capacity, ratios=ratios,
+                                          latent_size=latent_size, n_out=1, kernel_size=3, dilations=dil, **extra),
+                      vq_cls=partial(quantization.ResidualVectorQuantization, num_quantizers=num_quantizers,
+                                     dim=latent_size, codebook_size=codebook_size),
+                      num_quantizers=num_quantizers, noise_augmentation=noise_augmentation)
+    else:
+        raise ValueError(encoder_kind)
+    dec_latent = latent_size + noise_augmentation      # core.get_augmented_latent_size (v2.gin:24-26,47)
     if noise:   # configs/v2_small.gin:42-57
         extra_dec = dict(noise_module=partial(blocks.NoiseGeneratorV2, hidden_size=64, data_size=n_band,
                                               ratios=[2, 2, 2], noise_bands=32))
     else:
         extra_dec = {}
     dec = partial(blocks.GeneratorV2, data_size=n_band, capacity=capacity, ratios=ratios,
-                  latent_size=latent_size, kernel_size=3, dilations=dil, amplitude_modulation=True, **extra,
+                  latent_size=dec_latent, kernel_size=3, dilations=dil, amplitude_modulation=True, **extra,
                   **extra_dec)
     common = dict(out_size=1, capacity=disc_capacity or capacity, n_layers=4, stride=4)
     mpd = partial(discriminator.MultiPeriodDiscriminator, periods=[2, 3, 5, 7, 11],
                   convnet=partial(discriminator.ConvNet, conv=nn.Conv2d, kernel_size=(5, 1), **common))
     msd = partial(discriminator.MultiScaleDiscriminator, n_discriminators=3,
                   convnet=partial(discriminator.ConvNet, conv=nn.Conv1d, kernel_size=15, **common))
-    disc = partial(discriminator.CombineDiscriminators, discriminators=[mpd, msd])
+    if discriminator_kind == "v2":
+        disc = partial(discriminator.CombineDiscriminators, discriminators=[mpd, msd])
+    elif discriminator_kind == "descript":
+        disc = descript_discriminator.DescriptDiscriminator
+    elif discriminator_kind == "spectral":   # configs/spectral_discriminator.gin
+        mssd = partial(discriminator.MultiScaleSpectralDiscriminator, scales=[4096, 2048, 1024, 512, 256],
+                       convnet=partial(discriminator.EncodecConvNet, capacity=spectral_capacity))
+        disc = partial(discriminator.CombineDiscriminators, discriminators=[msd, mssd])
+    else:
+        raise ValueError(discriminator_kind)
     stft = partial(losses.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128], sample_rate=sampling_rate,
                    magnitude=True)
-    dist = partial(losses.AudioDistanceV1, multiscale_stft=stft, log_epsilon=1e-7)
+    dist = partial(losses.AudioDistanceV1, multiscale_stft=stft, log_epsilon=log_epsilon)
     model = RAVE(latent_size=latent_size, sampling_rate=sampling_rate,
                  pqmf=partial(pqmf.CachedPQMF, attenuation=100, n_band=n_band),
                  encoder=enc, decoder=dec, discriminator=disc, phase_1_duration=1000000,
                  gan_loss=losses.hinge_gan, valid_signal_crop=True,
                  feature_matching_fun=partial(losses.mean_difference, norm="L1", relative=True),
-                 num_skipped_features=1, audio_distance=dist, multiband_audio_distance=dist,
+                 num_skipped_features=num_skipped_features, audio_distance=dist, multiband_audio_distance=dist,
                  weights={"feature_matching": 20}, update_discriminator_every=update_discriminator_every,
                  n_channels=n_channels, n_bands=n_band)
     cc.set_default_padding_mode("centered")
     blocks.set_dilated_unit_activation(None)
     return model
+
+
+def build_v3(n_channels: int = 2, causal: bool = True, **kw) -> RAVE:
+    """configs/v3.gin (+ causal.gin; BASELINE config 5 is stereo): v2 + adain.gin + snake.gin +
+    descript_discriminator.gin."""
+    d = dict(n_channels=n_channels, causal=causal, snake=True, adain=True, discriminator_kind="descript")
+    d.update(kw)
+    return build_v2(**d)
+
+
+def build_discrete(spectral: bool = True, **kw) -> RAVE:
+    """configs/discrete.gin (+ spectral_discriminator.gin; BASELINE config 4): RATIOS [4,4,2,2], EncoderV2(n_out=1)
+    + 16-stage RVQ (1024 codes) + 128 noise channels, log_epsilon 1, num_skipped_features 0."""
+    d = dict(ratios=(4, 4, 2, 2), encoder_kind="discrete", noise_augmentation=128, log_epsilon=1.0,
+             num_skipped_features=0, discriminator_kind="spectral" if spectral else "v2")
+    d.update(kw)
+    return build_v2(**d)
