@@ -11,6 +11,7 @@
 // per output phase (alpha_h < sh, alpha_w < sw), with dy * act'(y) formed while staging.
 // The weight gradient reduces over 2-D chunks (rk x wk positions of dy) per batch item; split-K partials
 // + ordered reduction keep it bitwise deterministic.
+#include <cstdlib>
 #include <mutex>
 #include "conv_params.hpp"
 
@@ -31,6 +32,9 @@ struct Conv2P {
     int TQ, TR, tq_shift, tr_shift, nb, tiles_q, tiles_r;
     int PH, PW, PWp, chp;           // staged patch per (batch item, channel): PH x PW, row pitch PWp, plane pitch chp
     int ck, wlds_floats;
+    unsigned magic_pw, magic_ph, magic_ck;   // ceil(2^32/d) reciprocals (0 encodes d == 1); operands stay < 2^20
+    int ni, stage_floats;                    // LDS-DMA pipeline: 64-float DMA slots per plane, floats per stage
+    unsigned in_bytes, w_bytes;
     int mul_act, epi_act;
     float mul_slope, epi_slope;
     int nphase;
@@ -49,11 +53,15 @@ struct Wgrad2P {
     int rk, wk, wk_shift;           // dy chunk: rk rows x wk columns (wk = power of two >= 2)
     int chunks_r, chunks_w, total_chunks, chunks_per_z;
     int pr, PH, PW, PWp, chp, nc_max;
+    unsigned magic_pw, magic_ph;
     int minh, minw;
     int r_act;
     float r_slope;
     int offh[kMaxTaps], offw[kMaxTaps];
 };
+
+// n / d for n * d < 2^32 with magic = ceil(2^32 / d); magic == 0 encodes d == 1
+__device__ __forceinline__ int mdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv2d_igemm_kernel(const Conv2P p) {
@@ -105,36 +113,59 @@ __global__ __launch_bounds__(WM* WN * 64) void conv2d_igemm_kernel(const Conv2P 
     for (int c0 = 0; c0 < p.C && ntaps > 0; c0 += p.ck) {
         __syncthreads();
         // ---- stage the 2-D input patches (zero fill by coordinates = all four paddings) ----
-        const int nrows = p.nb * p.ck * p.PH;
-        for (int row = wave; row < nrows; row += NW) {
-            const int bc = row / p.PH, phh = row - bc * p.PH;
-            const int bl = bc / p.ck, c = bc - bl * p.ck;
-            const int b = b0 + bl, ch = c0 + c, h = h0 + phh;
-            float* dst = x_lds + bc * p.chp + phh * p.PWp;
-            const bool ok = b < p.B && ch < p.C && h >= 0 && h < p.in_h;
-            const long base = (((long)b * p.C + ch) * p.in_h + h) * p.in_w;
-            for (int w = lane; w < p.PW; w += 64) {
-                const int gw = w0 + w;
-                float v = 0.f;
-                if (ok && gw >= 0 && gw < p.in_w) {
-                    v = p.in[base + gw];
-                    if (p.in_mul) v *= rh_act_grad(p.in_mul[base + gw], p.mul_act, p.mul_slope, 0.f);
+        // flat element index -> (batch item, channel, patch row, column); U loads are issued before the first
+        // LDS store so that one global-memory latency is paid per U elements, not per element
+        constexpr int U = 8;
+        const int total = p.nb * p.ck * p.PH * p.PW;
+        for (int e0 = tid; e0 < total; e0 += NT * U) {
+            float v[U];
+            int dsto[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * NT;
+                v[u] = 0.f;
+                dsto[u] = -1;
+                if (e < total) {
+                    const int row = mdiv(e, p.magic_pw), w = e - row * p.PW;
+                    const int bc = mdiv(row, p.magic_ph), phh = row - bc * p.PH;
+                    const int bl = mdiv(bc, p.magic_ck), c = bc - bl * p.ck;
+                    const int b = b0 + bl, ch = c0 + c, h = h0 + phh, gw = w0 + w;
+                    dsto[u] = bc * p.chp + phh * p.PWp + w;
+                    if (b < p.B && ch < p.C && h >= 0 && h < p.in_h && gw >= 0 && gw < p.in_w) {
+                        const long idx = (((long)b * p.C + ch) * p.in_h + h) * p.in_w + gw;
+                        v[u] = p.in[idx];
+                        if (p.in_mul) v[u] *= rh_act_grad(p.in_mul[idx], p.mul_act, p.mul_slope, 0.f);
+                    }
                 }
-                dst[w] = v;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dsto[u] >= 0) x_lds[dsto[u]] = v[u];
         }
         // ---- stage the weight tile [tap][c][BM] ----
         constexpr int V = BM / 4;
-        const int wrows = ntaps * p.ck;
-        for (int e = tid; e < wrows * V; e += NT) {
-            const int kr = e / V, v4 = e - kr * V;
-            const int t = kr / p.ck, c = kr - t * p.ck;
-            const int ch = c0 + c;
-            const int m = m0 + v4 * 4;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (ch < p.C && m < p.Mp)
-                val = *reinterpret_cast<const f32x4*>(wp + ((long)t * p.C + ch) * p.Mp + m);
-            *reinterpret_cast<f32x4*>(w_lds + kr * BM + v4 * 4) = val;
+        constexpr int UW = 4;
+        const int wtotal = ntaps * p.ck * V;
+        for (int e0 = tid; e0 < wtotal; e0 += NT * UW) {
+            f32x4 val[UW];
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const int e = e0 + u * NT;
+                val[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < wtotal) {
+                    const int kr = e / V, v4 = e - kr * V;
+                    const int t = mdiv(kr, p.magic_ck), c = kr - t * p.ck;
+                    const int ch = c0 + c;
+                    const int m = m0 + v4 * 4;
+                    if (ch < p.C && m < p.Mp)
+                        val[u] = *reinterpret_cast<const f32x4*>(wp + ((long)t * p.C + ch) * p.Mp + m);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UW; ++u) {
+                const int e = e0 + u * NT;
+                if (e < wtotal) *reinterpret_cast<f32x4*>(w_lds + e * 4) = val[u];
+            }
         }
         __syncthreads();
         // ---- MFMA over (tap, channel pair) ----
@@ -185,6 +216,181 @@ __global__ __launch_bounds__(WM* WN * 64) void conv2d_igemm_kernel(const Conv2P 
     }
 }
 
+
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr unsigned kOOB = 0x80000000u;   // >= any descriptor size we accept -> the DMA writes zeros
+constexpr int kNI = 20;                  // max 64-float DMA slots per staged plane (PH*PW <= 1280)
+
+// Same GEMM as conv2d_igemm_kernel, software-pipelined with asynchronous global->LDS DMA
+// (buffer_load ... lds): two LDS stages, one barrier per K chunk, no staging registers.  A staged plane is
+// the compact PH x PW patch; lane l of DMA slot i always fetches patch element 64 i + l, so its in-plane
+// source offset (or the out-of-range marker that makes the DMA write 0.0: all four zero paddings) is
+// computed ONCE per workgroup -- per K chunk only a scalar plane base changes.
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv2d_dma_kernel(const Conv2P p) {
+    constexpr int BM = TM * WM * 32;
+    constexpr int NW = WM * WN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    const int phase = blockIdx.z;
+    const int ntaps = p.ph_ntaps[phase];
+    const int tap0 = p.ph_tap0[phase];
+    const int minh = p.ph_minh[phase], minw = p.ph_minw[phase];
+    const unsigned wofs = (unsigned)p.ph_wofs[phase];
+
+    int bx = blockIdx.x;
+    const int tq = bx % p.tiles_q;
+    bx /= p.tiles_q;
+    const int tr = bx % p.tiles_r;
+    const int bt = bx / p.tiles_r;
+    const int b0 = bt * p.nb, r0 = tr * p.TR, q0 = tq * p.TQ;
+    const int m0 = blockIdx.y * BM;
+    const int h0 = r0 * p.is_h + minh, w0 = q0 * p.is_w + minw;
+
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, p.w_bytes, 0x00020000);
+
+    int xb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = (wn * TN + tn) * 32 + j;
+        const int ql = col & (p.TQ - 1);
+        const int rl = (col >> p.tq_shift) & (p.TR - 1);
+        const int bl = col >> (p.tq_shift + p.tr_shift);
+        xb[tn] = (bl * p.ck + kh) * p.chp + rl * p.is_h * p.PW + ql * p.is_w;
+    }
+    const int arow = wm * TM * 32 + j + kh * BM;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    unsigned xo[kNI];
+#pragma unroll
+    for (int i = 0; i < kNI; ++i) {
+        const int e = lane + 64 * i;
+        const int row = mdiv(e, p.magic_pw), w = e - row * p.PW;
+        const int h = h0 + row, gw = w0 + w;
+        const bool ok = i < p.ni && row < p.PH && h >= 0 && h < p.in_h && gw >= 0 && gw < p.in_w;
+        xo[i] = ok ? (unsigned)(h * p.in_w + gw) * 4u : kOOB;
+    }
+    const int planes = p.nb * p.ck;
+    const unsigned plane_bytes = (unsigned)p.in_h * (unsigned)p.in_w * 4u;
+    const int wrows = ntaps * p.ck;
+    const int w_instrs = (wrows * BM + 255) >> 8;   // 256 floats (64 lanes x 16 B) per DMA instruction
+
+    auto issue = [&](int c0, float* stage) {
+        for (int q = wave; q < w_instrs; q += NW) {   // weights: LDS image [tap][c][BM], flat
+            const int f = q * 256 + lane * 4;
+            const int kr = f / BM, col = f - kr * BM;
+            const int t = mdiv(kr, p.magic_ck), c = kr - t * p.ck;
+            const int ch = c0 + c, m = m0 + col;
+            unsigned off = kOOB;
+            if (kr < wrows && ch < p.C && m < p.Mp) off = (wofs + (unsigned)(t * p.C + ch) * p.Mp + m) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(stage + q * 256), 16, off, 0, 0, 0);
+        }
+        float* xs = stage + p.wlds_floats;
+        for (int pl = wave; pl < planes; pl += NW) {
+            const int bl = mdiv(pl, p.magic_ck), c = pl - bl * p.ck;
+            const int b = b0 + bl, ch = c0 + c;
+            const bool dead = b >= p.B || ch >= p.C;
+            const unsigned base = (unsigned)(b * p.C + ch) * plane_bytes;
+            float* dst = xs + pl * p.chp;
+#pragma unroll
+            for (int i = 0; i < kNI; ++i) {
+                if (i < p.ni) {
+                    const unsigned off = (dead || xo[i] == kOOB) ? kOOB : base + xo[i];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_void*)(dst + i * 64), 4, off, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int nchunks = ntaps > 0 ? (p.C + p.ck - 1) / p.ck : 0;
+    if (nchunks > 0) issue(0, smem);
+    for (int i = 0; i < nchunks; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // chunk i landed for every wave; everyone is done with the other stage
+        if (i + 1 < nchunks) issue((i + 1) * p.ck, smem + ((i + 1) & 1) * p.stage_floats);
+        const float* w_lds = smem + (i & 1) * p.stage_floats;
+        const float* x_lds = w_lds + p.wlds_floats;
+        for (int t = 0; t < ntaps; ++t) {
+            const int toff = (p.offh[tap0 + t] - minh) * p.PW + (p.offw[tap0 + t] - minw);
+            const float* wl = w_lds + t * p.ck * BM + arow;
+            const float* xl = x_lds + toff;
+            int c = 0;
+            for (; c + 8 <= p.ck; c += 8) {     // 4 k-steps per trip, all LDS reads in flight before the MFMAs
+                float a[4][TM], b[4][TN];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) a[u][tm] = wl[(c + 2 * u) * BM + tm * 32];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) b[u][tn] = xl[xb[tn] + (c + 2 * u) * p.chp];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][tm], b[u][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; c < p.ck; c += 2) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[tm] = wl[c * BM + tm * 32];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) b[tn] = xl[xb[tn] + c * p.chp];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + output activation ----
+    const int oph_h = p.ph_oph_h[phase], oph_w = p.ph_oph_w[phase];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = (wn * TN + tn) * 32 + j;
+        const int ql = col & (p.TQ - 1);
+        const int rl = (col >> p.tq_shift) & (p.TR - 1);
+        const int bl = col >> (p.tq_shift + p.tr_shift);
+        const int r = r0 + rl, q = q0 + ql, b = b0 + bl;
+        if (r >= p.rows || q >= p.qcols || b >= p.B) continue;
+        const int orow = r * p.os_h + oph_h, ocol = q * p.os_w + oph_w;
+        if (orow >= p.out_h || ocol >= p.out_w) continue;
+        const long cbase = ((long)b * p.M * p.out_h + orow) * p.out_w + ocol;
+        const int plane = p.out_h * p.out_w;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = m0 + (wm * TM + tm) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+                if (m < p.M) {
+                    float v = acc[tm][tn][rr];
+                    if (p.bias) v += p.bias[m];
+                    p.out[cbase + (long)m * plane] = rh_act_apply(v, p.epi_act, p.epi_slope, 0.f);
+                }
+            }
+        }
+    }
+}
+
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad2d_kernel(const Wgrad2P p) {
     constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
@@ -229,32 +435,58 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad2d_kernel(const Wgrad2P p) {
         const int b = t2 / p.chunks_r;
         const int hr0 = cr * p.rk, wc0 = cw * p.wk;
         __syncthreads();
-        for (int r = wave; r < BM; r += NW) {
-            const int m = m0 + r;
-            float* dst = r_lds + r * p.pr;
-            for (int e = lane; e < kelems; e += 64) {
-                const int rr = e >> p.wk_shift, ww = e & (p.wk - 1);
-                const int h = hr0 + rr, w = wc0 + ww;
-                float v = 0.f;
-                if (m < p.M && h < p.r_h && w < p.r_w) {
-                    const long idx = (((long)b * p.M + m) * p.r_h + h) * p.r_w + w;
-                    v = p.R[idx];
-                    if (p.Rmul) v *= rh_act_grad(p.Rmul[idx], p.r_act, p.r_slope, 0.f);
+        constexpr int U = 8;
+        constexpr int NT = NW * 64;
+        {   // R tile: [BM][rk*wk] (kelems is a power of two)
+            const int ksh = __builtin_ctz(kelems);
+            const int total = BM << ksh;
+            for (int e0 = tid; e0 < total; e0 += NT * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + u * NT;
+                    v[u] = 0.f;
+                    if (e < total) {
+                        const int r = e >> ksh, k = e & (kelems - 1);
+                        const int rr = k >> p.wk_shift, ww = k & (p.wk - 1);
+                        const int m = m0 + r, h = hr0 + rr, w = wc0 + ww;
+                        if (m < p.M && h < p.r_h && w < p.r_w) {
+                            const long idx = (((long)b * p.M + m) * p.r_h + h) * p.r_w + w;
+                            v[u] = p.R[idx];
+                            if (p.Rmul) v[u] *= rh_act_grad(p.Rmul[idx], p.r_act, p.r_slope, 0.f);
+                        }
+                    }
                 }
-                dst[e] = v;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + u * NT;
+                    if (e < total) r_lds[(e >> ksh) * p.pr + (e & (kelems - 1))] = v[u];
+                }
             }
         }
-        const int h0 = hr0 * p.is_h + p.minh, w0 = wc0 * p.is_w + p.minw;
-        const int srows = p.nc_max * p.PH;
-        for (int row = wave; row < srows; row += NW) {
-            const int cc = row / p.PH, phh = row - cc * p.PH;
-            const int c = c_lo + cc, h = h0 + phh;
-            const bool ok = c < p.C && h >= 0 && h < p.s_h;
-            const long base = (((long)b * p.C + c) * p.s_h + h) * p.s_w;
-            float* dst = s_lds + cc * p.chp + phh * p.PWp;
-            for (int w = lane; w < p.PW; w += 64) {
-                const int gw = w0 + w;
-                dst[w] = (ok && gw >= 0 && gw < p.s_w) ? p.S[base + gw] : 0.f;
+        {   // S patches: [nc_max][PH][PW]
+            const int h0 = hr0 * p.is_h + p.minh, w0 = wc0 * p.is_w + p.minw;
+            const int total = p.nc_max * p.PH * p.PW;
+            for (int e0 = tid; e0 < total; e0 += NT * U) {
+                float v[U];
+                int dsto[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + u * NT;
+                    v[u] = 0.f;
+                    dsto[u] = -1;
+                    if (e < total) {
+                        const int row = mdiv(e, p.magic_pw), w = e - row * p.PW;
+                        const int cc = mdiv(row, p.magic_ph), phh = row - cc * p.PH;
+                        const int c = c_lo + cc, h = h0 + phh, gw = w0 + w;
+                        dsto[u] = cc * p.chp + phh * p.PWp + w;
+                        if (c < p.C && h >= 0 && h < p.s_h && gw >= 0 && gw < p.s_w)
+                            v[u] = p.S[(((long)b * p.C + c) * p.s_h + h) * p.s_w + gw];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (dsto[u] >= 0) s_lds[dsto[u]] = v[u];
             }
         }
         __syncthreads();
@@ -315,6 +547,7 @@ __global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restric
 }
 
 inline int round32(int m) { return (m + 31) & ~31; }
+inline unsigned magic32(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 inline int pow2ceil(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -446,15 +679,24 @@ int launch2(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what) {
     p.PWp = p.PW | 1;
     p.chp = (p.PH * p.PWp) | 1;
     const int per_ch = maxtaps * BM + p.nb * p.chp;
-    int ck = (15 * 1024) / per_ch;
+    static const int budget = [] {
+        const char* e = getenv("RH_CONV2D_STAGE_FLOATS");
+        return e ? atoi(e) : 15 * 1024;
+    }();
+    int ck = budget / per_ch;
     ck &= ~1;
     if (ck > 32) ck = 32;
     if (ck < 2) ck = 2;
     const int cmax = (p.C + 1) & ~1;
     if (ck > cmax) ck = cmax;
     p.ck = ck;
+    p.magic_pw = magic32(p.PW);
+    p.magic_ph = magic32(p.PH);
+    p.magic_ck = magic32(ck);
     p.wlds_floats = maxtaps * ck * BM;
     const size_t lds = sizeof(float) * ((size_t)p.wlds_floats + (size_t)p.nb * ck * p.chp);
+    RH_REQUIRE((long)p.nb * ck * p.PH * p.PW < (1l << 20) && (long)maxtaps * ck * BM < (1l << 20), RH_ERR_UNSUPPORTED,
+               "%s: tile too large", what);
     RH_REQUIRE(lds <= 160 * 1024, RH_ERR_UNSUPPORTED, "%s: tile needs %zu B of LDS", what, lds);
     auto kern = conv2d_igemm_kernel<TM, TN, WM, WN>;
     static std::once_flag once;
@@ -469,12 +711,99 @@ int launch2(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what) {
     return rh_check_launch(what);
 }
 
+
+// LDS-DMA variant: returns RH_ERR_UNSUPPORTED (without setting a message the caller shows) when the geometry
+// does not fit its staging scheme; the caller then uses the register-staged kernel.
+template <int TM, int TN, int WM, int WN>
+int launch2_dma(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what, bool* done) {
+    constexpr int BM = TM * WM * 32, BN = TN * WN * 32;
+    *done = false;
+    if (p.in_mul) return RH_OK;
+    const long in_b = (long)p.B * p.C * p.in_h * p.in_w * 4, w_b = 0;
+    (void)w_b;
+    if (in_b >= (1l << 31)) return RH_OK;
+    int span_h = 0, span_w = 0, maxtaps = 1;
+    long wfloats = 0;
+    for (int i = 0; i < t.nphase; ++i) {
+        span_h = span_h > t.maxh[i] - t.minh[i] ? span_h : t.maxh[i] - t.minh[i];
+        span_w = span_w > t.maxw[i] - t.minw[i] ? span_w : t.maxw[i] - t.minw[i];
+        maxtaps = maxtaps > t.ntaps[i] ? maxtaps : t.ntaps[i];
+        wfloats += (long)t.ntaps[i] * p.C * p.Mp;
+    }
+    if (wfloats * 4 >= (1l << 31)) return RH_OK;
+    int TQ = pow2ceil(p.qcols) < BN ? pow2ceil(p.qcols) : BN;
+    int TR = pow2ceil(p.rows) < BN / TQ ? pow2ceil(p.rows) : BN / TQ;
+    auto patch = [&](int tq_, int tr_) { return (long)((tr_ - 1) * p.is_h + span_h + 1) * ((tq_ - 1) * p.is_w + span_w + 1); };
+    while (patch(TQ, TR) > 64 * kNI) {
+        if (TR > 1) TR >>= 1;
+        else if (TQ > 16) TQ >>= 1;
+        else return RH_OK;
+    }
+    p.TQ = TQ; p.TR = TR;
+    p.nb = BN / (TQ * TR);
+    p.tq_shift = __builtin_ctz(TQ);
+    p.tr_shift = __builtin_ctz(TR);
+    p.tiles_q = rh_cdiv(p.qcols, TQ);
+    p.tiles_r = rh_cdiv(p.rows, TR);
+    p.PH = (TR - 1) * p.is_h + span_h + 1;
+    p.PW = (TQ - 1) * p.is_w + span_w + 1;
+    p.PWp = p.PW;
+    p.ni = (p.PH * p.PW + 63) / 64;
+    p.chp = p.ni * 64 + 32;                       // % 64 == 32: the two k-halves of a wave hit disjoint banks
+    static const int budget = [] {
+        const char* e = getenv("RH_CONV2D_DMA_STAGE_FLOATS");
+        return e ? atoi(e) : 8 * 1024;
+    }();
+    const int per_ch = maxtaps * BM + p.nb * p.chp;
+    int ck = budget / per_ch;
+    if (ck >= 8) ck &= ~7;
+    else ck &= ~1;
+    if (ck > 32) ck = 32;
+    if (ck < 2) ck = 2;
+    const int cmax = (p.C + 1) & ~1;
+    if (ck > cmax) ck = cmax;
+    p.ck = ck;
+    p.magic_pw = magic32(p.PW);
+    p.magic_ph = magic32(p.PH);
+    p.magic_ck = magic32(ck);
+    p.wlds_floats = (maxtaps * ck * BM + 255) & ~255;
+    p.stage_floats = p.wlds_floats + p.nb * ck * p.chp;
+    const size_t lds = sizeof(float) * 2 * (size_t)p.stage_floats;
+    if (lds > 160 * 1024) return RH_OK;
+    p.in_bytes = (unsigned)in_b;
+    p.w_bytes = (unsigned)(wfloats * 4);
+    auto kern = conv2d_dma_kernel<TM, TN, WM, WN>;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+    });
+    const long gx = (long)rh_cdiv(p.B, p.nb) * p.tiles_r * p.tiles_q;
+    if (gx >= (1l << 31)) return RH_OK;
+    dim3 grid((unsigned)gx, rh_cdiv(p.M, BM), p.nphase);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+    *done = true;
+    return rh_check_launch(what);
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch2_any(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what) {
+    static const bool no_dma = getenv("RH_CONV2D_NODMA") != nullptr;
+    if (!no_dma) {
+        bool done = false;
+        Conv2P q = p;
+        if (int e = launch2_dma<TM, TN, WM, WN>(q, t, stream, what, &done)) return e;
+        if (done) return RH_OK;
+    }
+    return launch2<TM, TN, WM, WN>(p, t, stream, what);
+}
+
 int launch_conv2(Conv2P& p, const Plan2& t, hipStream_t stream, const char* what) {
     if (p.B <= 0) return RH_OK;
-    if (p.M <= 32) return launch2<1, 2, 1, 4>(p, t, stream, what);
-    if (p.M <= 64) return launch2<2, 1, 1, 4>(p, t, stream, what);
-    if (p.M % 96 == 0) return launch2<3, 1, 1, 4>(p, t, stream, what);
-    return launch2<2, 2, 2, 2>(p, t, stream, what);
+    if (p.M <= 32) return launch2_any<1, 2, 1, 4>(p, t, stream, what);
+    if (p.M <= 64) return launch2_any<2, 1, 1, 4>(p, t, stream, what);
+    if (p.M % 96 == 0) return launch2_any<3, 1, 1, 4>(p, t, stream, what);
+    return launch2_any<2, 2, 2, 2>(p, t, stream, what);
 }
 
 struct W2Plan {
@@ -515,8 +844,14 @@ W2Plan plan_w2(Wgrad2P& p) {
         p.chp = (p.PH * p.PWp) | 1;
         p.pr = rk * p.wk + 2;
         w.lds = sizeof(float) * ((size_t)w.bm * p.pr + (size_t)p.nc_max * p.chp);
-        if (w.lds <= 80 * 1024 || rk == 1) break;
+        static const size_t cap = [] {
+            const char* e = getenv("RH_WGRAD2D_LDS_BYTES");
+            return e ? (size_t)atol(e) : (size_t)80 * 1024;
+        }();
+        if (w.lds <= cap || rk == 1) break;
     }
+    p.magic_pw = magic32(p.PW);
+    p.magic_ph = magic32(p.PH);
     p.chunks_r = rh_cdiv(p.r_h, p.rk);
     p.chunks_w = rh_cdiv(p.r_w, p.wk);
     p.total_chunks = p.B * p.chunks_r * p.chunks_w;

@@ -408,10 +408,18 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, wp_b = ctx.saved_tensors
         d = ctx.d
-        dref = C.byref(d)
         dy = _chk(dy, "dy")
         s = L.stream()
         dx = dw = db = None
+        if y is not None:
+            # one elementwise pass forms dy * act'(y); the gradient kernels then run activation-free
+            # (which lets the data gradient use the LDS-DMA pipeline: DMA cannot transform data in flight)
+            g = torch.empty_like(dy)
+            L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y), d.act, d.act_slope, dy.numel(), L.ptr(g), s), "act_bwd")
+            dy, y = g, None
+            d = L.Conv2dDesc.from_buffer_copy(d)
+            d.act = ACT_NONE
+        dref = C.byref(d)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(_launch2("conv2d_dgrad", d, lambda: L.lib.rh_conv2d_bwd_data_f32(
