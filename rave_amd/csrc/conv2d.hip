@@ -54,6 +54,8 @@ struct Wgrad2P {
     int chunks_r, chunks_w, total_chunks, chunks_per_z;
     int pr, PH, PW, PWp, chp, nc_max;
     unsigned magic_pw, magic_ph;
+    int nr, ns, r_floats, stage_floats;   // LDS-DMA pipeline: 64-float slots per R row / S plane, floats per stage
+    unsigned r_bytes, s_bytes;
     int minh, minw;
     int r_act;
     float r_slope;
@@ -522,28 +524,203 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad2d_kernel(const Wgrad2P p) {
     }
 }
 
-// dbias[m] = sum_{b,h,w} dy * act'(y)   (one block per channel, fixed reduction order)
-__global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                          float* __restrict__ db, int B, int M, long plane, int act,
-                                                          float slope) {
-    __shared__ float red[256];
-    const int m = blockIdx.x;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const long base = ((long)b * M + m) * plane;
-        for (long e = threadIdx.x; e < plane; e += 256) {
-            float v = dy[base + e];
-            if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
-            s += v;
+
+constexpr int kNR = 4;    // 64-float DMA slots per R row   (rk*wk <= 256)
+constexpr int kNS = 16;   // 64-float DMA slots per S plane (PH*PW <= 1024)
+
+// Weight gradient for M <= 32 (the spectral discriminators' 32-channel stacks), LDS-DMA double-buffered:
+// a workgroup owns 32 x (TN*128) of dW (a range of (c, tap) columns) for its K slice; per chunk of rk x wk
+// positions of dy it stages the 32 dy rows and the input patches of its channels with asynchronous DMA
+// (per-lane offsets inside a row / plane precomputed once; only validity bits and scalar bases per chunk).
+template <int TN>
+__global__ __launch_bounds__(256) void wgrad2d_dma_kernel(const Wgrad2P p) {
+    constexpr int BN = TN * 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * 32, col0 = blockIdx.x * BN, z = blockIdx.z;
+    const int ncols = p.C * p.T;
+    const int c_lo = col0 / p.T;
+    const int nc = min(p.nc_max, p.C - c_lo);
+
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
+    const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.S), 0, p.s_bytes, 0x00020000);
+
+    int sb[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        int col = col0 + (wave * TN + tn) * 32 + j;
+        col = min(col, ncols - 1);
+        const int c = col / p.T, t = col - c * p.T;
+        sb[tn] = (c - c_lo) * p.chp + (p.offh[t] - p.minh) * p.PW + (p.offw[t] - p.minw) + kh * p.is_w;
+    }
+    const int ar = j * p.pr + kh;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+
+    // per-lane slot geometry: (row, col) inside the dy chunk / the input patch, packed, and the element offset
+    unsigned rp[kNR], ro[kNR], sp[kNS], so[kNS];
+#pragma unroll
+    for (int i = 0; i < kNR; ++i) {
+        const int k = lane + 64 * i;
+        const int rr = k >> p.wk_shift, ww = k & (p.wk - 1);
+        rp[i] = ((unsigned)rr << 16) | (unsigned)ww;
+        ro[i] = (unsigned)(rr * p.r_w + ww) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < kNS; ++i) {
+        const int e = lane + 64 * i;
+        const int row = mdiv(e, p.magic_pw), w = e - row * p.PW;
+        sp[i] = (i < p.ns && row < p.PH) ? (((unsigned)row << 16) | (unsigned)w) : 0xffffffffu;
+        so[i] = (unsigned)(row * p.s_w + w) * 4u;
+    }
+
+    auto issue = [&](int ch, float* stage) {
+        const int cw = ch % p.chunks_w;
+        const int t2 = ch / p.chunks_w;
+        const int cr = t2 % p.chunks_r;
+        const int b = t2 / p.chunks_r;
+        const int hr0 = cr * p.rk, wc0 = cw * p.wk;
+        unsigned rmask = 0;
+#pragma unroll
+        for (int i = 0; i < kNR; ++i) {
+            const int rr = rp[i] >> 16, ww = rp[i] & 0xffff;
+            if (i < p.nr && hr0 + rr < p.r_h && wc0 + ww < p.r_w) rmask |= 1u << i;
+        }
+        for (int r = wave; r < 32; r += 4) {
+            const int m = m0 + r;
+            const bool dead = m >= p.M;
+            const unsigned base = (unsigned)(((b * p.M + m) * p.r_h + hr0) * p.r_w + wc0) * 4u;
+            float* dst = stage + r * p.pr;
+#pragma unroll
+            for (int i = 0; i < kNR; ++i) {
+                if (i < p.nr) {
+                    const unsigned off = (dead || !((rmask >> i) & 1u)) ? kOOB : base + ro[i];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lds_void*)(dst + i * 64), 4, off, 0, 0, 0);
+                }
+            }
+        }
+        const int h0 = hr0 * p.is_h + p.minh, w0 = wc0 * p.is_w + p.minw;
+        unsigned smask = 0;
+#pragma unroll
+        for (int i = 0; i < kNS; ++i) {
+            const int h = h0 + (int)(sp[i] >> 16), gw = w0 + (int)(sp[i] & 0xffff);
+            if (sp[i] != 0xffffffffu && h >= 0 && h < p.s_h && gw >= 0 && gw < p.s_w) smask |= 1u << i;
+        }
+        float* xs = stage + p.r_floats;
+        const unsigned sbase0 = (unsigned)((h0 * p.s_w + w0) * 4);      // may wrap; only used where the sum is valid
+        const unsigned plane_bytes = (unsigned)p.s_h * (unsigned)p.s_w * 4u;
+        for (int cc = wave; cc < p.nc_max; cc += 4) {
+            const bool dead = cc >= nc;
+            const unsigned base = (unsigned)(b * p.C + c_lo + cc) * plane_bytes + sbase0;
+            float* dst = xs + cc * p.chp;
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                if (i < p.ns) {
+                    const unsigned off = (dead || !((smask >> i) & 1u)) ? kOOB : base + so[i];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void*)(dst + i * 64), 4, off, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int ch0 = z * p.chunks_per_z;
+    const int ch1 = min(ch0 + p.chunks_per_z, p.total_chunks);
+    if (ch0 < ch1) issue(ch0, smem);
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int i = ch - ch0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ch + 1 < ch1) issue(ch + 1, smem + ((i + 1) & 1) * p.stage_floats);
+        const float* r_lds = smem + (i & 1) * p.stage_floats + ar;
+        const float* s_lds = smem + (i & 1) * p.stage_floats + p.r_floats;
+        for (int rr = 0; rr < p.rk; ++rr) {
+            const float* rl = r_lds + rr * p.wk;
+            const float* sl = s_lds + rr * p.is_h * p.PW;
+            int ww = 0;
+            for (; ww + 8 <= p.wk; ww += 8) {
+                float a[4], bb[4][TN];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = rl[ww + 2 * u];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bb[u][tn] = sl[sb[tn] + (ww + 2 * u) * p.is_w];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb[u][tn], acc[tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; ww < p.wk; ww += 2) {
+                const float a = rl[ww];
+                float bb[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bb[tn] = sl[sb[tn] + ww * p.is_w];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[tn], acc[tn], 0, 0, 0);
+            }
         }
     }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+    float* out = p.out + (long)z * p.M * ncols;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = col0 + (wave * TN + tn) * 32 + j;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < p.M) out[(long)m * ncols + col] = acc[tn][r];
+        }
     }
-    if (threadIdx.x == 0) db[m] = red[0];
+}
+
+// dbias[m] = sum_{b,h,w} dy * act'(y): grid (M, kBiasSlices) partial sums over interleaved 1024-element segments
+// of the (b, plane) index space, then an ordered pass over the slices (deterministic).
+constexpr int kBiasSlices = 64;
+
+__global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ part, int B, int M, long plane, int act,
+                                                          float slope) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, sl = blockIdx.y;
+    const long segs_per_b = (plane + 1023) / 1024;
+    const long nseg = (long)B * segs_per_b;
+    float s = 0.f;
+    for (long sg = sl; sg < nseg; sg += kBiasSlices) {
+        const long b = sg / segs_per_b, e0 = (sg - b * segs_per_b) * 1024;
+        const long base = ((long)b * M + m) * plane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long e = e0 + u * 256 + threadIdx.x;
+            if (e < plane) {
+                float v = dy[base + e];
+                if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
+                s += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)m * kBiasSlices + sl] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void bias_grad2d_finalize_kernel(const float* __restrict__ part, float* __restrict__ db,
+                                                                  int M) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int i = 0; i < kBiasSlices; ++i) s += part[(long)m * kBiasSlices + i];
+    db[m] = s;
 }
 
 inline int round32(int m) { return (m + 31) & ~31; }
@@ -879,6 +1056,89 @@ int launch_w2(const Wgrad2P& p, const W2Plan& w, hipStream_t stream) {
     return rh_check_launch("conv2d_bwd_weight");
 }
 
+
+// LDS-DMA weight-gradient plan (M <= 32, no fused activation derivative); false = use the generic kernel
+bool plan_w2_dma(Wgrad2P& p, W2Plan* w, int* tn_out) {
+    static const bool off = getenv("RH_WGRAD2D_NODMA") != nullptr;
+    if (off || p.M > 32 || p.Rmul) return false;
+    const long rb = (long)p.B * p.M * p.r_h * p.r_w * 4, sbytes = (long)p.B * p.C * p.s_h * p.s_w * 4;
+    if (rb >= (1l << 31) || sbytes >= (1l << 31)) return false;
+    const int ncols = p.C * p.T;
+    const int TN = ncols <= 128 ? 1 : (ncols <= 256 ? 2 : 4);
+    const int BN = TN * 128;
+    p.nc_max = (BN - 1) / p.T + 2;
+    if (p.nc_max > p.C) p.nc_max = p.C;
+    int span_h = 0, span_w = 0, minh = 0, minw = 0;
+    for (int t = 0; t < p.T; ++t) {
+        if (t == 0 || p.offh[t] < minh) minh = p.offh[t];
+        if (t == 0 || p.offw[t] < minw) minw = p.offw[t];
+    }
+    for (int t = 0; t < p.T; ++t) {
+        span_h = span_h > p.offh[t] - minh ? span_h : p.offh[t] - minh;
+        span_w = span_w > p.offw[t] - minw ? span_w : p.offw[t] - minw;
+    }
+    p.minh = minh;
+    p.minw = minw;
+    static const int stage_cap = [] {
+        const char* e = getenv("RH_WGRAD2D_DMA_STAGE_FLOATS");
+        return e ? atoi(e) : 10 * 1024;
+    }();
+    int wk = pow2ceil(p.r_w) < 64 ? pow2ceil(p.r_w) : 64;
+    if (wk < 2) wk = 2;
+    int rk = 128 / wk > 1 ? 128 / wk : 1;                       // ~128 positions of dy per chunk
+    for (;;) {
+        if (rk * wk < 64) rk = 64 / wk;                          // a DMA slot is 64 floats
+        p.wk = wk; p.rk = rk;
+        p.wk_shift = __builtin_ctz(wk);
+        p.PH = (rk - 1) * p.is_h + span_h + 1;
+        p.PW = (wk - 1) * p.is_w + span_w + 1;
+        p.PWp = p.PW;
+        p.nr = rk * wk / 64;
+        p.ns = (p.PH * p.PW + 63) / 64;
+        p.pr = rk * wk + 2;
+        p.chp = p.ns * 64 + 1;
+        p.r_floats = 32 * p.pr;
+        p.stage_floats = p.r_floats + p.nc_max * p.chp;
+        const bool fits = p.nr <= kNR && p.ns <= kNS && p.stage_floats <= stage_cap;
+        if (fits) break;
+        if (rk * wk > 64 && rk > 1) rk >>= 1;                    // shrink the chunk, rows first
+        else if (wk > 8) { wk >>= 1; rk = 64 / wk > 1 ? 64 / wk : 1; }
+        else if (p.nr <= kNR && p.ns <= kNS && 2 * p.stage_floats * 4 <= 160 * 1024) break;   // over the soft cap only
+        else return false;
+    }
+    p.magic_pw = magic32(p.PW);
+    p.magic_ph = magic32(p.PH);
+    p.chunks_r = rh_cdiv(p.r_h, p.rk);
+    p.chunks_w = rh_cdiv(p.r_w, p.wk);
+    p.total_chunks = p.B * p.chunks_r * p.chunks_w;
+    p.r_bytes = (unsigned)rb;
+    p.s_bytes = (unsigned)sbytes;
+    const int bxy = rh_cdiv(ncols, BN);
+    int Z = 1024 / bxy;
+    if (Z > p.total_chunks / 8) Z = p.total_chunks / 8;          // at least 8 chunks per slice
+    if (Z < 1) Z = 1;
+    p.chunks_per_z = rh_cdiv(p.total_chunks, Z);
+    w->Z = rh_cdiv(p.total_chunks, p.chunks_per_z);
+    w->bm = 32;
+    w->bn = BN;
+    w->lds = sizeof(float) * 2 * (size_t)p.stage_floats;
+    *tn_out = TN;
+    return true;
+}
+
+template <int TN>
+int launch_w2_dma(const Wgrad2P& p, const W2Plan& w, hipStream_t stream) {
+    auto kern = wgrad2d_dma_kernel<TN>;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+    });
+    dim3 grid(rh_cdiv(p.C * p.T, TN * 128), 1, w.Z);
+    hipLaunchKernelGGL(kern, grid, dim3(256), w.lds, stream, p);
+    return rh_check_launch("conv2d_bwd_weight");
+}
+
 void fill_w2(const rh_conv2d_desc* d, Wgrad2P* p) {
     *p = Wgrad2P{};
     p->B = d->batch; p->M = d->c_out; p->C = d->c_in; p->T = d->kh * d->kw;
@@ -972,8 +1232,15 @@ extern "C" int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d) {
     if (d->batch == 0) return 0;
     Wgrad2P p;
     fill_w2(d, &p);
-    const W2Plan w = plan_w2(p);
-    return w.Z > 1 ? (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
+    W2Plan w{};
+    int tn = 0;
+    // the fused activation derivative (act != NONE) takes the generic kernel; size for the larger of the two
+    Wgrad2P q = p;
+    int64_t need = 0;
+    if (plan_w2_dma(q, &w, &tn)) need = w.Z > 1 ? (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
+    const W2Plan g = plan_w2(p);
+    const int64_t need_g = g.Z > 1 ? (int64_t)g.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
+    return (need > need_g ? need : need_g) + (int64_t)d->c_out * kBiasSlices * (int64_t)sizeof(float);
 }
 
 extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x,
@@ -992,21 +1259,34 @@ extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy
         return RH_OK;
     }
     const float* ymul = d->act == RH_ACT_NONE ? nullptr : y;
+    const int64_t bias_ws = (int64_t)d->c_out * kBiasSlices * (int64_t)sizeof(float);
     if (dbias) {
-        hipLaunchKernelGGL(bias_grad2d_kernel, dim3(d->c_out), dim3(256), 0, stream, dy, ymul, dbias, d->batch,
-                           d->c_out, (long)d->h_out * d->w_out, d->act, d->act_slope);
+        RH_REQUIRE(workspace && workspace_bytes >= bias_ws, RH_ERR_WORKSPACE,
+                   "conv2d_bwd_weight: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)bias_ws);
+        float* part = (float*)workspace;       // the first c_out*64 floats; the split-K partials follow
+        hipLaunchKernelGGL(bias_grad2d_kernel, dim3(d->c_out, kBiasSlices), dim3(256), 0, stream, dy, ymul, part,
+                           d->batch, d->c_out, (long)d->h_out * d->w_out, d->act, d->act_slope);
         if (int e = rh_check_launch("conv2d_bias_grad")) return e;
+        hipLaunchKernelGGL(bias_grad2d_finalize_kernel, dim3(rh_cdiv(d->c_out, 64)), dim3(64), 0, stream,
+                           (const float*)part, dbias, d->c_out);
+        if (int e = rh_check_launch("conv2d_bias_grad_finalize")) return e;
     }
+    workspace = workspace ? (void*)((char*)workspace + bias_ws) : nullptr;
+    workspace_bytes = workspace_bytes > bias_ws ? workspace_bytes - bias_ws : 0;
     Wgrad2P p;
     fill_w2(d, &p);
     p.R = dy; p.Rmul = ymul; p.S = x;
-    const W2Plan w = plan_w2(p);
+    W2Plan w{};
+    int tn = 0;
+    const bool dma = plan_w2_dma(p, &w, &tn);
+    if (!dma) w = plan_w2(p);
     const int64_t need = w.Z > 1 ? (int64_t)w.Z * nw * (int64_t)sizeof(float) : 0;
     RH_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), RH_ERR_WORKSPACE,
                "conv2d_bwd_weight: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)need);
     p.out = w.Z > 1 ? (float*)workspace : dw;
     int e;
-    if (w.bm == 32) e = launch_w2<1, 2, 1, 4>(p, w, stream);
+    if (dma) e = tn == 1 ? launch_w2_dma<1>(p, w, stream) : (tn == 2 ? launch_w2_dma<2>(p, w, stream) : launch_w2_dma<4>(p, w, stream));
+    else if (w.bm == 32) e = launch_w2<1, 2, 1, 4>(p, w, stream);
     else if (w.bm == 64) e = launch_w2<2, 1, 1, 4>(p, w, stream);
     else if (w.bm == 96) e = launch_w2<3, 1, 1, 4>(p, w, stream);
     else e = launch_w2<2, 2, 2, 2>(p, w, stream);
