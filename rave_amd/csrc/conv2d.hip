@@ -682,47 +682,6 @@ __global__ __launch_bounds__(256) void wgrad2d_dma_kernel(const Wgrad2P p) {
     }
 }
 
-// dbias[m] = sum_{b,h,w} dy * act'(y): grid (M, kBiasSlices) partial sums over interleaved 1024-element segments
-// of the (b, plane) index space, then an ordered pass over the slices (deterministic).
-constexpr int kBiasSlices = 64;
-
-__global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                          float* __restrict__ part, int B, int M, long plane, int act,
-                                                          float slope) {
-    __shared__ float red[4];
-    const int m = blockIdx.x, sl = blockIdx.y;
-    const long segs_per_b = (plane + 1023) / 1024;
-    const long nseg = (long)B * segs_per_b;
-    float s = 0.f;
-    for (long sg = sl; sg < nseg; sg += kBiasSlices) {
-        const long b = sg / segs_per_b, e0 = (sg - b * segs_per_b) * 1024;
-        const long base = ((long)b * M + m) * plane;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long e = e0 + u * 256 + threadIdx.x;
-            if (e < plane) {
-                float v = dy[base + e];
-                if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
-                s += v;
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[(long)m * kBiasSlices + sl] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__global__ __launch_bounds__(64) void bias_grad2d_finalize_kernel(const float* __restrict__ part, float* __restrict__ db,
-                                                                  int M) {
-    const int m = blockIdx.x * 64 + threadIdx.x;
-    if (m >= M) return;
-    float s = 0.f;
-    for (int i = 0; i < kBiasSlices; ++i) s += part[(long)m * kBiasSlices + i];
-    db[m] = s;
-}
-
 inline int round32(int m) { return (m + 31) & ~31; }
 inline unsigned magic32(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 inline int pow2ceil(int v) {
@@ -1240,7 +1199,7 @@ extern "C" int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d) {
     if (plan_w2_dma(q, &w, &tn)) need = w.Z > 1 ? (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
     const W2Plan g = plan_w2(p);
     const int64_t need_g = g.Z > 1 ? (int64_t)g.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
-    return (need > need_g ? need : need_g) + (int64_t)d->c_out * kBiasSlices * (int64_t)sizeof(float);
+    return (need > need_g ? need : need_g) + rh_bias_grad_workspace(d->c_out);
 }
 
 extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x,
@@ -1259,17 +1218,14 @@ extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy
         return RH_OK;
     }
     const float* ymul = d->act == RH_ACT_NONE ? nullptr : y;
-    const int64_t bias_ws = (int64_t)d->c_out * kBiasSlices * (int64_t)sizeof(float);
+    const int64_t bias_ws = rh_bias_grad_workspace(d->c_out);
     if (dbias) {
         RH_REQUIRE(workspace && workspace_bytes >= bias_ws, RH_ERR_WORKSPACE,
                    "conv2d_bwd_weight: workspace %lld B < %lld B", (long long)workspace_bytes, (long long)bias_ws);
-        float* part = (float*)workspace;       // the first c_out*64 floats; the split-K partials follow
-        hipLaunchKernelGGL(bias_grad2d_kernel, dim3(d->c_out, kBiasSlices), dim3(256), 0, stream, dy, ymul, part,
-                           d->batch, d->c_out, (long)d->h_out * d->w_out, d->act, d->act_slope);
-        if (int e = rh_check_launch("conv2d_bias_grad")) return e;
-        hipLaunchKernelGGL(bias_grad2d_finalize_kernel, dim3(rh_cdiv(d->c_out, 64)), dim3(64), 0, stream,
-                           (const float*)part, dbias, d->c_out);
-        if (int e = rh_check_launch("conv2d_bias_grad_finalize")) return e;
+        // the first c_out*64 floats of the workspace; the split-K partials follow
+        if (int e = rh_bias_grad_launch(dy, ymul, (float*)workspace, dbias, d->batch, d->c_out,
+                                        (long)d->h_out * d->w_out, d->act, d->act_slope, stream))
+            return e;
     }
     workspace = workspace ? (void*)((char*)workspace + bias_ws) : nullptr;
     workspace_bytes = workspace_bytes > bias_ws ? workspace_bytes - bias_ws : 0;

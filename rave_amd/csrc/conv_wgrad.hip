@@ -132,23 +132,45 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     out[e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-// dbias[m] = sum_{b,n} dy[b][m][n]  (one block per channel, fixed reduction order)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
-                                                        int B, int M, int row) {
-    __shared__ float red[256];
-    const int m = blockIdx.x;
+// dbias[m] = sum_{b,h,w} dy * act'(y): grid (M, kBiasSlices) partial sums over interleaved 1024-element segments
+// of the (b, plane) index space, then an ordered pass over the slices (deterministic).
+constexpr int kBiasSlices = 64;
+
+__global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ part, int B, int M, long plane, int act,
+                                                          float slope) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, sl = blockIdx.y;
+    const long segs_per_b = (plane + 1023) / 1024;
+    const long nseg = (long)B * segs_per_b;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* src = dy + ((long)b * M + m) * row;
-        for (int e = threadIdx.x; e < row; e += 256) s += src[e];
+    for (long sg = sl; sg < nseg; sg += kBiasSlices) {
+        const long b = sg / segs_per_b, e0 = (sg - b * segs_per_b) * 1024;
+        const long base = ((long)b * M + m) * plane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long e = e0 + u * 256 + threadIdx.x;
+            if (e < plane) {
+                float v = dy[base + e];
+                if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
+                s += v;
+            }
+        }
     }
-    red[threadIdx.x] = s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) db[m] = red[0];
+    if (threadIdx.x == 0) part[(long)m * kBiasSlices + sl] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void bias_grad2d_finalize_kernel(const float* __restrict__ part, float* __restrict__ db,
+                                                                  int M) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int i = 0; i < kBiasSlices; ++i) s += part[(long)m * kBiasSlices + i];
+    db[m] = s;
 }
 
 
@@ -551,8 +573,9 @@ int64_t rh_wgrad_workspace(const rh_conv1d_desc* d) {
     WgradP p{};
     fill(d, &p);
     const WPlan w = plan(p);
-    if (w.Z <= 1) return 0;
-    return (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float);
+    const int64_t bias = rh_bias_grad_workspace(d->c_out);
+    if (w.Z <= 1) return bias;
+    return bias + (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float);
 }
 
 int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const float* alpha,
@@ -562,11 +585,17 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     if (!d->transposed) { p.R = dy; p.S = x; p.r_alpha = nullptr; p.s_alpha = alpha; }
     else                { p.R = x; p.S = dy; p.r_alpha = alpha; p.s_alpha = nullptr; }
     const long nw = (long)p.M * p.C * p.T;
+    const int64_t bias_ws = rh_bias_grad_workspace(d->c_out);
     if (dbias && d->batch > 0) {
-        const int row = d->l_out * d->inner;
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(d->c_out), dim3(256), 0, stream, dy, dbias, d->batch, d->c_out, row);
-        if (int e = rh_check_launch("conv1d_bias_grad")) return e;
+        RH_REQUIRE(ws && ws_bytes >= bias_ws, RH_ERR_WORKSPACE, "conv1d_bwd_weight: workspace %lld B < %lld B",
+                   (long long)ws_bytes, (long long)bias_ws);
+        // the first c_out*64 floats of the workspace; the split-K partials follow
+        if (int e = rh_bias_grad_launch(dy, nullptr, (float*)ws, dbias, d->batch, d->c_out,
+                                        (long)d->l_out * d->inner, RH_ACT_NONE, 0.f, stream))
+            return e;
     }
+    ws = ws ? (void*)((char*)ws + bias_ws) : nullptr;
+    ws_bytes = ws_bytes > bias_ws ? ws_bytes - bias_ws : 0;
     if (p.B <= 0 || p.r_row <= 0) {
         (void)hipMemsetAsync(dw, 0, nw * sizeof(float), stream);
         if (dbias) (void)hipMemsetAsync(dbias, 0, d->c_out * sizeof(float), stream);
@@ -596,4 +625,14 @@ int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipS
     if (n <= 0) return RH_OK;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 256)), dim3(256), 0, stream, part, out, n, Z);
     return rh_check_launch(what);
+}
+
+int64_t rh_bias_grad_workspace(int M) { return (int64_t)M * kBiasSlices * (int64_t)sizeof(float); }
+
+int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db, int B, int M, long plane, int act,
+                        float slope, hipStream_t stream) {
+    hipLaunchKernelGGL(bias_grad2d_kernel, dim3(M, kBiasSlices), dim3(256), 0, stream, dy, y, part, B, M, plane, act, slope);
+    if (int e = rh_check_launch("bias_grad")) return e;
+    hipLaunchKernelGGL(bias_grad2d_finalize_kernel, dim3(rh_cdiv(M, 64)), dim3(64), 0, stream, (const float*)part, db, M);
+    return rh_check_launch("bias_grad_finalize");
 }

@@ -16,6 +16,10 @@ torch.manual_seed(0)
 if which == "encodec":
     model = D.MultiScaleSpectralDiscriminator([4096, 2048, 1024, 512, 256], partial(D.EncodecConvNet, capacity=32), n_channels=1)
     x = torch.randn(N, 1, 65536, device=dev) * 0.1
+elif which == "v2":
+    from rave_amd import model as M
+    model = M.build_v2().discriminator
+    x = torch.randn(N, 1, 65536, device=dev) * 0.1
 else:
     model = DD.DescriptDiscriminator(n_channels=2)
     x = torch.randn(N, 2, 65536, device=dev) * 0.1
