@@ -470,7 +470,9 @@ WPlan plan(const WgradP& p) {
     static const int rk_env = [] { const char* e = getenv("RH_WGRAD_RK"); return e ? atoi(e) : 0; }();
     // reduction chunk: 32 positions (3 workgroups per CU) measured best, except pointwise convs
     // whose S tile has one row per column (64 keeps the DMA instructions full)
+    static const int rk_inner_env = [] { const char* e = getenv("RH_WGRAD_RK_INNER"); return e ? atoi(e) : 0; }();
     int rk = ((rk_env > 0 ? rk_env : 32) / p.inner) & ~1;
+    if (p.inner > 1) rk = ((rk_inner_env > 0 ? rk_inner_env : 32) / p.inner) & ~1;
     if (rk < 2) rk = 2;
     const int r_rows = p.r_row / p.inner;
     if (r_rows < rk) rk = (r_rows + 1) & ~1;  // short sequences: do not pad the K chunk with zeros
