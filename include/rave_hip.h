@@ -277,9 +277,14 @@ int rh_stft_frame_bwd_f32(const float* dframes, const float* window, int64_t row
 int64_t rh_spectral_distance_workspace_bytes(void);
 int rh_spectral_distance_fwd_f32(const float* sx, const float* sy, int64_t n_complex, float eps, float* sums,
                                  void* workspace, int64_t workspace_bytes, rh_stream_t stream);
-/* d distance / d Sx and / d Sy (either output may be NULL), scaled by the device scalar grad_out[0]. */
+/* d distance / d Sx and / d Sy (either output may be NULL), scaled by the device scalar grad_out[0].
+ * half_bins = 0: the plain gradients.  half_bins = n_fft/2+1 (spectra laid out (..., half_bins)): the interior
+ * bins are halved, which makes the outputs the operand of the UNNORMALISED C2R transform that is the adjoint of
+ * rfft -- d distance / d frames = irfft(dsx, n_fft, norm="forward") -- instead of autograd's zero-fill + copy +
+ * C2C + real-part chain. */
 int rh_spectral_distance_bwd_f32(const float* sx, const float* sy, const float* sums, const float* grad_out,
-                                 int64_t n_complex, float eps, float* dsx, float* dsy, rh_stream_t stream);
+                                 int64_t n_complex, float eps, float* dsx, float* dsy, int32_t half_bins,
+                                 rh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -207,10 +207,17 @@ __global__ __launch_bounds__(256) void spectral_finalize_kernel(const float* __r
 // gradients w.r.t. both complex spectrograms: d|z|/dz = z/|z| (0 at z = 0, as torch's abs backward)
 __global__ __launch_bounds__(256) void spectral_bwd_kernel(const float2* __restrict__ sx, const float2* __restrict__ sy,
                                                            const float* __restrict__ sums, const float* __restrict__ gout,
-                                                           long n, float eps, float2* __restrict__ dsx, float2* __restrict__ dsy) {
+                                                           long n, float eps, float2* __restrict__ dsx, float2* __restrict__ dsy,
+                                                           int half_bins) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    const float g = gout[0];
+    // half_bins > 0: emit the operand of the C2R transform that is the adjoint of rfft -- interior bins halved
+    // (dx_n = Re sum_k g_k e^{+i theta} = irfft_unnormalised(h), h_0 = g_0, h_{N/2} = g_{N/2}, h_k = g_k / 2)
+    float g = gout[0];
+    if (half_bins > 0) {
+        const int k = (int)(e % half_bins);
+        if (k != 0 && k != half_bins - 1) g *= 0.5f;
+    }
     const float A = sums[0], B = sums[1];
     const float invB = 1.f / B, invN = 1.f / (float)n;
     const float2 x = sx[e], y = sy[e];
@@ -411,10 +418,12 @@ extern "C" int rh_spectral_distance_fwd_f32(const float* sx, const float* sy, in
 }
 
 extern "C" int rh_spectral_distance_bwd_f32(const float* sx, const float* sy, const float* sums, const float* grad_out,
-                                            int64_t n_complex, float eps, float* dsx, float* dsy, rh_stream_t stream) {
-    RH_REQUIRE(sx && sy && sums && grad_out && n_complex > 0, RH_ERR_INVALID, "spectral_distance_bwd: bad arguments");
+                                            int64_t n_complex, float eps, float* dsx, float* dsy, int32_t half_bins,
+                                            rh_stream_t stream) {
+    RH_REQUIRE(sx && sy && sums && grad_out && n_complex > 0 && half_bins >= 0, RH_ERR_INVALID,
+               "spectral_distance_bwd: bad arguments");
     hipLaunchKernelGGL(spectral_bwd_kernel, dim3(blocks_for(n_complex)), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)sx, (const float2*)sy, sums, grad_out, (long)n_complex, eps, (float2*)dsx, (float2*)dsy);
+                       (const float2*)sx, (const float2*)sy, sums, grad_out, (long)n_complex, eps, (float2*)dsx, (float2*)dsy, half_bins);
     return rh_check_launch("spectral_bwd");
 }
 

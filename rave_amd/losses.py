@@ -77,9 +77,13 @@ class AudioDistanceV1(nn.Module):
             # fused path: magnitude, both distances and their reductions in one HIP kernel per scale
             # (rh_spectral_distance_*), the STFTs themselves on rocFFT
             from . import ops
+            ms = self.multiscale_stft
+            xr, yr = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
             distance = 0.
-            for a, b in zip(self.multiscale_stft.complex_stfts(x), self.multiscale_stft.complex_stfts(y)):
-                distance = distance + ops.spectral_distance(a, b, float(self.log_epsilon))
+            for s in ms.scales:
+                w = getattr(ms, f"window_{s}")
+                distance = distance + ops.stft_distance(ops.stft_frames(xr, w, s, s // 4),
+                                                        ops.stft_frames(yr, w, s, s // 4), float(self.log_epsilon))
             return {"spectral_distance": distance}
         stfts_x = self.multiscale_stft(x)
         stfts_y = self.multiscale_stft(y)

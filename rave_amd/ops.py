@@ -617,12 +617,55 @@ class _SpectralDistanceFn(torch.autograd.Function):
         L.check(L.lib.rh_spectral_distance_bwd_f32(
             L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), L.ptr(sums), L.ptr(g), sx.numel(), ctx.eps,
             None if dsx is None else torch.view_as_real(dsx).data_ptr(),
-            None if dsy is None else torch.view_as_real(dsy).data_ptr(), L.stream()), "spectral_distance_bwd")
+            None if dsy is None else torch.view_as_real(dsy).data_ptr(), 0, L.stream()), "spectral_distance_bwd")
         return dsx, dsy, None
 
 
 def spectral_distance(sx: Tensor, sy: Tensor, eps: float) -> Tensor:
     return _SpectralDistanceFn.apply(sx, sy, eps)
+
+
+class _StftDistanceFn(torch.autograd.Function):
+    """AudioDistanceV1 on one STFT scale from the windowed FRAMES (rows, n_frames, n_fft) of both signals:
+    rfft (rocFFT) + fused distance kernel forward; backward = fused gradient kernel emitting the operand of the
+    C2R adjoint of rfft + one unnormalised irfft per signal (instead of autograd's FftR2CBackward: complex
+    zero-fill + copy + C2C + real part)."""
+
+    @staticmethod
+    def forward(ctx, fx, fy, eps: float):
+        fx = _chk(fx, "frames_x"); fy = _chk(fy, "frames_y")
+        if fx.shape != fy.shape:
+            raise RuntimeError("rave_amd stft_distance: frame tensors differ in shape")
+        n_fft = fx.shape[-1]
+        sx = torch.fft.rfft(fx, dim=-1)
+        sy = torch.fft.rfft(fy, dim=-1)
+        n = sx.numel()
+        sums = torch.empty(3, device=fx.device, dtype=torch.float32)
+        nbytes = L.lib.rh_spectral_distance_workspace_bytes()
+        ws = torch.empty(nbytes // 4, device=fx.device, dtype=torch.float32)
+        L.check(L.lib.rh_spectral_distance_fwd_f32(L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), n, eps,
+                                                   L.ptr(sums), L.ptr(ws), nbytes, L.stream()), "spectral_distance_fwd")
+        ctx.save_for_backward(sx, sy, sums)
+        ctx.eps, ctx.n_fft = eps, n_fft
+        return sums[0] / sums[1] + sums[2] / n
+
+    @staticmethod
+    def backward(ctx, g):
+        sx, sy, sums = ctx.saved_tensors
+        g = g.contiguous().reshape(1).float()
+        hx = torch.empty_like(sx) if ctx.needs_input_grad[0] else None
+        hy = torch.empty_like(sy) if ctx.needs_input_grad[1] else None
+        L.check(L.lib.rh_spectral_distance_bwd_f32(
+            L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), L.ptr(sums), L.ptr(g), sx.numel(), ctx.eps,
+            None if hx is None else torch.view_as_real(hx).data_ptr(),
+            None if hy is None else torch.view_as_real(hy).data_ptr(), sx.shape[-1], L.stream()), "spectral_distance_bwd")
+        dfx = torch.fft.irfft(hx, n=ctx.n_fft, dim=-1, norm="forward") if hx is not None else None
+        dfy = torch.fft.irfft(hy, n=ctx.n_fft, dim=-1, norm="forward") if hy is not None else None
+        return dfx, dfy, None
+
+
+def stft_distance(frames_x: Tensor, frames_y: Tensor, eps: float) -> Tensor:
+    return _StftDistanceFn.apply(frames_x, frames_y, eps)
 
 
 class _AvgPool2Fn(torch.autograd.Function):

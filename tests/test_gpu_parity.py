@@ -817,3 +817,27 @@ def test_rvq_kmeans_init_and_discrete_encoder(dev):
         q1 = m.layers[0](z)[0]
         q2 = m(z)[0]
     assert float((z - q2).pow(2).mean()) < float((z - q1).pow(2).mean()) < float(z.pow(2).mean())
+
+
+@pytest.mark.parametrize("n_fft", [128, 2048])
+def test_stft_distance_c2r_adjoint_vs_torch_autograd(dev, ops, n_fft):
+    """rave/core.py:330-344 from windowed frames: forward value and d/d frames (backward = fused gradient kernel +
+    unnormalised C2R, the adjoint of rfft) against torch autograd through rfft on the CPU in float64."""
+    g = torch.Generator().manual_seed(n_fft)
+    fx = torch.randn(3, 17, n_fft, generator=g)
+    fy = fx + 0.3 * torch.randn(3, 17, n_fft, generator=g)
+    eps = 1e-3
+
+    def ref(a, b):
+        sa, sb = torch.fft.rfft(a, dim=-1).abs(), torch.fft.rfft(b, dim=-1).abs()
+        return ((sa - sb) ** 2).mean() / (sa ** 2).mean() + (torch.log(sa + eps) - torch.log(sb + eps)).abs().mean()
+
+    ad, bd = fx.double().requires_grad_(True), fy.double().requires_grad_(True)
+    r = ref(ad, bd)
+    (3.0 * r).backward()
+    ag, bg = fx.to(dev).requires_grad_(True), fy.to(dev).requires_grad_(True)
+    d = ops.stft_distance(ag, bg, eps)
+    assert abs(float(d.detach()) - float(r.detach())) <= 2e-5 * abs(float(r.detach()))
+    (3.0 * d).backward()
+    assert rel_l2(ag.grad, ad.grad) < 1e-4
+    assert rel_l2(bg.grad, bd.grad) < 1e-4
