@@ -637,8 +637,11 @@ class _StftDistanceFn(torch.autograd.Function):
         if fx.shape != fy.shape:
             raise RuntimeError("rave_amd stft_distance: frame tensors differ in shape")
         n_fft = fx.shape[-1]
-        sx = torch.fft.rfft(fx, dim=-1)
-        sy = torch.fft.rfft(fy, dim=-1)
+        from . import fft as F
+        # the frames are scratch produced by the framing kernel (its backward only needs the window): the FFT
+        # may overwrite them
+        sx = F.rfft_last(fx)
+        sy = F.rfft_last(fy)
         n = sx.numel()
         sums = torch.empty(3, device=fx.device, dtype=torch.float32)
         nbytes = L.lib.rh_spectral_distance_workspace_bytes()
@@ -659,8 +662,9 @@ class _StftDistanceFn(torch.autograd.Function):
             L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), L.ptr(sums), L.ptr(g), sx.numel(), ctx.eps,
             None if hx is None else torch.view_as_real(hx).data_ptr(),
             None if hy is None else torch.view_as_real(hy).data_ptr(), sx.shape[-1], L.stream()), "spectral_distance_bwd")
-        dfx = torch.fft.irfft(hx, n=ctx.n_fft, dim=-1, norm="forward") if hx is not None else None
-        dfy = torch.fft.irfft(hy, n=ctx.n_fft, dim=-1, norm="forward") if hy is not None else None
+        from . import fft as F
+        dfx = F.irfft_last_unnormalized(hx, ctx.n_fft) if hx is not None else None
+        dfy = F.irfft_last_unnormalized(hy, ctx.n_fft) if hy is not None else None
         return dfx, dfy, None
 
 

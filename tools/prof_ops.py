@@ -17,4 +17,18 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     m.training_step(x.detach().clone(), 3)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60))
-print(prof.key_averages(group_by_stack_n=6).table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=50, max_src_column_width=110))
+for ev in prof.key_averages(group_by_stack_n=10):
+    if ev.key in ("aten::clone", "aten::copy_", "aten::contiguous", "aten::fill_", "aten::add", "aten::mul"):
+        print(f"{ev.key:18s} n={ev.count:3d} cuda={ev.device_time_total:9.1f}us  | " + " <- ".join(x.strip()[-70:] for x in ev.stack[:6]))
+
+from collections import Counter
+cnt = Counter()
+for ev in prof.events():
+    if ev.name in ("aten::clone", "aten::copy_"):
+        chain, q = [], ev.cpu_parent
+        while q is not None and len(chain) < 4:
+            chain.append(q.name[:60])
+            q = q.cpu_parent
+        cnt[(ev.name, " <- ".join(chain))] += 1
+for (k, c), n in cnt.most_common(20):
+    print(f"PARENT {k:12s} x{n:3d}  {c}")
