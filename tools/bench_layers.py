@@ -77,6 +77,23 @@ for (name, ci, co, lin, k, st, dil, pl, pr, tr, act) in layers:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
         res.append(us)
+    if os.environ.get("CONCURRENT"):
+        # dgrad on the current stream and wgrad on a side stream at the same time (both only need dy and x)
+        side = torch.cuda.Stream()
+        s2 = side.cuda_stream
+        fw2 = lambda: L.lib.rh_conv1d_bwd_weight_f32(r, L.ptr(dy), L.ptr(x), None, L.ptr(dw), None, L.ptr(ws), nws, s2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        e0.record()
+        for _ in range(n):
+            side.wait_stream(torch.cuda.current_stream())
+            L.check(fns[1]()); L.check(fw2())
+            torch.cuda.current_stream().wait_stream(side)
+        e1.record()
+        torch.cuda.synchronize()
+        both = e0.elapsed_time(e1) * 1e3 / n
+        print("    dgrad || wgrad on two streams: %.1f us (serial %.1f)" % (both, res[1] + res[2]))
     tot[0] += flop; tot[1] += res[0]; tot[2] += res[1]; tot[3] += res[2]
     print("%-24s %9.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (name, flop / 1e9, res[0], flop / res[0] / 1e6, res[1], flop / res[1] / 1e6, res[2], flop / res[2] / 1e6))
 print("TOTAL (one of each)      %9.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (tot[0] / 1e9, tot[1], tot[0] / tot[1] / 1e6, tot[2], tot[0] / tot[2] / 1e6, tot[3], tot[0] / tot[3] / 1e6))
