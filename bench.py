@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--config", choices=["v2", "discrete", "v3"], default="v2",
                     help="v2 = BASELINE configs[1]/[2] (the metric's config); discrete = configs[3] (RVQ + spectral "
                          "discriminator); v3 = configs[4] (stereo, causal, snake, descript discriminator)")
+    ap.add_argument("--skip-dead-grads", action="store_true",
+                    help="opt-in (NOT the headline): skip gradients the reference computes and discards "
+                         "(rave_amd.model.RAVE.skip_dead_grads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -132,6 +135,7 @@ def main():
     ddp.broadcast_module(m)
     gen_opt, dis_opt = m.configure_optimizers()
     m.warmed_up = args.phase == "gan"
+    m.skip_dead_grads = bool(args.skip_dead_grads)
     gen_params = list(m.encoder.parameters()) + list(m.decoder.parameters())
     use_ddp = world > 1 or force_dist
     red_gen = ddp.GradReducer(gen_params, force=force_dist) if use_ddp else None
@@ -182,7 +186,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config} config, batch {args.batch} {'stereo' if n_ch == 2 else 'mono'} 44.1 kHz "
                                f"n_signal={args.n_signal}, "
-                               f"{'VAE' if args.phase == 'vae' else 'VAE+GAN'}-phase training step per GPU",
+                               f"{'VAE' if args.phase == 'vae' else 'VAE+GAN'}-phase training step per GPU"
+                               + (" [opt-in: dead gradients skipped]" if args.skip_dead_grads else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "per_gpu_samples_per_s": samples / dt / world,
     }

@@ -70,6 +70,11 @@ class RAVE(nn.Module):
         self.logged: Dict[str, torch.Tensor] = {}
         self._opts = None
         self._prep = None
+        # OPT-IN (default off = the reference's exact work per step): skip gradient work
+        # whose result the reference computes and then discards -- on generator steps the discriminator's weight
+        # gradients (dis_opt.zero_grad() runs before they could be used), on discriminator steps everything behind
+        # y_raw / x_raw (gen_opt.zero_grad() discards it).  Parameter trajectories are identical.
+        self.skip_dead_grads = False
 
     def prepare_weights(self, with_discriminator: bool = False):
         """Refresh weight norm + packed weights of every conv in two launches (see rave_amd/prep.py);
@@ -167,9 +172,20 @@ class RAVE(nn.Module):
             distances[f"fullband_{k}"] = self.weights["audio_distance"] * v
 
         feature_matching_distance = 0.
+        dis_step = bool(self.warmed_up) and not (batch_idx % self.update_discriminator_every)
+        frozen = []
         if self.warmed_up:
-            xy = torch.cat([x_raw, y_raw], 0)
+            if self.skip_dead_grads and dis_step:
+                xy = torch.cat([x_raw.detach(), y_raw.detach()], 0)
+            else:
+                xy = torch.cat([x_raw, y_raw], 0)
+            if self.skip_dead_grads and not dis_step:
+                frozen = [q for q in self.discriminator.parameters() if q.requires_grad]
+                for q in frozen:
+                    q.requires_grad_(False)
             features = self.discriminator(xy)
+            for q in frozen:
+                q.requires_grad_(True)
             feature_real, feature_fake = self.split_features(features)
             loss_dis = 0
             loss_adv = 0
@@ -194,7 +210,7 @@ class RAVE(nn.Module):
             loss_gen["feature_matching"] = self.weights["feature_matching"] * feature_matching_distance
             loss_gen["adversarial"] = self.weights["adversarial"] * loss_adv
 
-        if not (batch_idx % self.update_discriminator_every) and self.warmed_up:
+        if dis_step:
             dis_opt.zero_grad()
             loss_dis.backward()
             if grad_sync is not None:

@@ -841,3 +841,27 @@ def test_stft_distance_c2r_adjoint_vs_torch_autograd(dev, ops, n_fft):
     (3.0 * d).backward()
     assert rel_l2(ag.grad, ad.grad) < 1e-4
     assert rel_l2(bg.grad, bd.grad) < 1e-4
+
+
+def test_skip_dead_grads_keeps_the_parameter_trajectory(dev):
+    """Opt-in rave_amd.model.RAVE.skip_dead_grads: the gradients it skips are ones the
+    reference zeroes before use, so 8 alternating GAN-phase steps must leave bit-identical parameters."""
+    from rave_amd import model as M
+
+    def run(skip):
+        torch.manual_seed(0)
+        m = M.build_v2(capacity=8, latent_size=16, disc_capacity=8).to(dev).train()
+        m.configure_optimizers()
+        m.warmed_up = True
+        m.skip_dead_grads = skip
+        g = torch.Generator().manual_seed(3)
+        x = (0.2 * torch.randn(2, 1, 32768, generator=g)).to(dev)
+        eps = torch.randn(2, 16, 16, generator=g).to(dev)
+        for i in range(8):
+            m.training_step(x.detach().clone(), i, eps=eps)
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    a, b = run(False), run(True)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
