@@ -94,7 +94,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
     const int wrows = ntaps * p.ck;
     const int w_instrs = (wrows * BM + 255) >> 8;   // 256 floats (64 lanes x 16 B) per DMA instruction
     const int xrows = p.nb * p.ck;
-    const int x_instrs = xrows * p.segs;            // 64 floats (64 lanes x 4 B) per DMA instruction
 
     // ---- VEC: 16-byte DMA, per-lane source offsets precomputed once per workgroup ----------------
     // Each lane owns up to kNX float4 slots of the input tile and kNWS of the weight tile; per K chunk

@@ -176,7 +176,6 @@ __global__ __launch_bounds__(64) void bias_grad2d_finalize_kernel(const float* _
 
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOOB = 0x80000000u;
-constexpr int kPR = 65;   // max LDS pitch of an R row: 64 reduction elements + 1 (conflict-free column reads)
 // exact n / d for n < 2^32 / d with magic = ceil(2^32 / d) (d >= 2); magic == 0 encodes d == 1
 __device__ __forceinline__ unsigned mdiv(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
 

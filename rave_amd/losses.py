@@ -1,8 +1,9 @@
 """Losses of RAVE.training_step (rave/core.py) -- beside the HIP hot path ("next" #1).
 
-The STFTs run on stock PyTorch-ROCm (torch.stft -> rocFFT); on the GPU everything after them
-(magnitude, linear + log distance, the three reductions and the whole backward down to the complex
-spectrogram gradients) is ONE fused HIP kernel pair per scale (rh_spectral_distance_{fwd,bwd}_f32).
+On the GPU one STFT scale is: HIP framing kernel (centre + reflect pad + Hann) -> rocFFT R2C called through
+hipFFT directly (rave_amd/fft.py) -> ONE fused HIP kernel for magnitude, linear + log distance and the three
+reductions; backward: fused gradient kernel emitting the operand of the C2R adjoint of rfft -> rocFFT C2R ->
+HIP framing adjoint (rave_amd.ops.stft_distance).  Only the FFT itself is library code.
 The CPU branch keeps the reference's torch formulation and is what the parity tests compare with.
 """
 from __future__ import annotations
