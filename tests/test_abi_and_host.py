@@ -154,3 +154,53 @@ def test_conv2d_discriminator_mirrors_have_reference_state_dict_layout(golden_di
     assert {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith(".window")} == g["descript"]["shapes"]
     with __import__("pytest").raises(RuntimeError):
         m(torch.zeros(1, 2, 2048))      # CPU tensors: the HIP path has no CPU fallback
+
+
+_INTEGRATION_SCRIPT = r'''
+import json, sys
+sys.dont_write_bytecode = True
+root, use_hip = sys.argv[1], sys.argv[2] == "hip"
+sys.path.insert(0, root); sys.path.insert(0, root + "/oracle")
+if use_hip:                                  # INTEGRATION.md section 1: swap the operator package before `import rave`
+    import rave_amd.cc as cc_hip
+    sys.modules["cached_conv"] = cc_hip
+from ref_import import import_reference
+rave = import_reference()
+import torch
+from rave import blocks, pqmf
+torch.manual_seed(0)
+dil = [[1, 3, 9], [1, 3, 9], [1, 3, 9], [1, 3]]
+mods = dict(
+    enc=blocks.VariationalEncoder(lambda n_channels=1: blocks.EncoderV2(data_size=16, capacity=8, ratios=[4, 4, 4, 2],
+        latent_size=16, n_out=2, kernel_size=3, dilations=dil, n_channels=n_channels)),
+    dec=blocks.GeneratorV2(data_size=16, capacity=8, ratios=[4, 4, 4, 2], latent_size=16, kernel_size=3, dilations=dil,
+        amplitude_modulation=True),
+    pq=pqmf.CachedPQMF(attenuation=100, n_band=16))
+out = {k: {n: list(t.shape) for n, t in m.state_dict().items()} for k, m in mods.items()}
+import cached_conv
+convs = [type(m).__module__ for m in mods["enc"].modules() if type(m).__name__ in ("Conv1d", "ConvTranspose1d")]
+print("RESULT" + json.dumps(dict(shapes=out, conv_modules=sorted(set(convs)), cc=cached_conv.__name__)))
+'''
+
+
+def test_reference_blocks_build_on_the_drop_in_operator_package():
+    """INTEGRATION.md section 1, exercised: with ``sys.modules['cached_conv'] = rave_amd.cc`` the UNMODIFIED reference
+    ``rave.blocks`` / ``rave.pqmf`` construct on the HIP operator classes and expose exactly the state_dict layout
+    they have on the (restated) cached_conv package.  Construction only -- no compute without a GPU."""
+    import json, os, subprocess, sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference/rave"):
+        pytest.skip("reference tree not present (GPU box)")
+
+    def run(kind):
+        r = subprocess.run([sys.executable, "-c", _INTEGRATION_SCRIPT, root, kind], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+
+    ref, hip = run("shim"), run("hip")
+    assert hip["cc"] == "rave_amd.cc" and ref["cc"] == "cached_conv"
+    assert hip["conv_modules"] == ["rave_amd.cc"]
+    # buffers the real package may add for streaming ("...pad") are not part of either build
+    assert hip["shapes"] == ref["shapes"]
