@@ -115,4 +115,48 @@ class CachedPQMF(nn.Module):
         return ops.pqmf_synthesis(x, self.inverse_conv.weight, self.inverse_conv._pad)
 
 
-PQMF = CachedPQMF
+class PQMF(nn.Module):
+    """rave/pqmf.py:179-242, the non-cached filterbank (``polyphase_forward/inverse`` :92-134 or
+    ``classic_forward/inverse`` :137-176; not bound by any shipped .gin, kept as the cross-check the reference
+    itself uses).  state_dict: buffers ``hk``, ``h`` only.  Both analysis variants equal CachedPQMF.forward
+    (same 512 taps, pad 256); both synthesis variants equal CachedPQMF.inverse advanced by one frame of 16 samples
+    (the polyphase form pads 17 + 17 and crops two frames, :129-133), which on the HIP kernel is the pad pair
+    (15, 17) instead of (16, 16).  The kernel operands are non-persistent buffers derived from ``hk``."""
+
+    def __init__(self, attenuation, n_band, polyphase=True, n_channels=1):
+        super().__init__()
+        if n_band != 16 and n_band != 1:
+            raise NotImplementedError("rave_amd.pqmf: the HIP kernels implement the 16-band bank of the shipped configs")
+        if polyphase:
+            power = math.log2(n_band)
+            assert power == math.floor(power), "when using the polyphase algorithm, n_band must be a power of 2"
+        h = torch.from_numpy(get_prototype(attenuation, n_band)).float()
+        hk = center_pad_next_pow_2(get_qmf_bank(h, n_band))
+        self.register_buffer("hk", hk)
+        self.register_buffer("h", h)
+        self.n_band = n_band
+        self.polyphase = polyphase
+        self.n_channels = n_channels
+        m = hk.shape[0]
+        self.register_buffer("_w_fwd", make_odd(hk).unsqueeze(1).contiguous(), persistent=False)
+        self.register_buffer("_w_inv", make_odd(hk.flip(-1).reshape(m, -1, m).permute(2, 0, 1)).contiguous(),
+                             persistent=False)
+
+    def forward(self, x):
+        if x.ndim == 2:
+            return torch.stack([self.forward(x[i]) for i in range(x.shape[0])])
+        if self.n_band == 1:
+            return x
+        half = self.hk.shape[-1] // 2
+        return ops.pqmf_analysis(x, self._w_fwd, (half, half))
+
+    def inverse(self, x):
+        if x.ndim == 2:
+            if self.n_channels == 1:
+                return self.inverse(x[0]).unsqueeze(0)
+            x = x.split(self.n_channels, -2)
+            return torch.stack([self.inverse(xi) for xi in x])
+        if self.n_band == 1:
+            return x
+        taps = self._w_inv.shape[-1] - 1          # 32 polyphase taps (+1 zero from make_odd)
+        return ops.pqmf_synthesis(x, self._w_inv, (taps // 2 - 1, taps // 2 + 1))

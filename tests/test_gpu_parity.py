@@ -865,3 +865,20 @@ def test_skip_dead_grads_keeps_the_parameter_trajectory(dev):
     assert a.keys() == b.keys()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("polyphase", [True, False])
+def test_noncached_pqmf_mirror_vs_oracle(dev, polyphase):
+    """rave.pqmf.PQMF (polyphase / classic forms, rave/pqmf.py:179-242) on the HIP PQMF kernels vs the oracle
+    restatement of those forms."""
+    from rave_amd import pqmf as P
+    m = P.PQMF(attenuation=100, n_band=16, polyphase=polyphase).to(dev)
+    assert set(m.state_dict().keys()) == {"hk", "h"}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 1, 8192, generator=g)
+    y = torch.randn(3, 16, 512, generator=g)
+    hk = m.hk.cpu()
+    fa = O.pqmf_polyphase_forward if polyphase else O.pqmf_classic_forward
+    fs = O.pqmf_polyphase_inverse if polyphase else O.pqmf_classic_inverse
+    assert rel_l2(m(x.to(dev)), fa(x, hk)) < TOL_OP
+    assert rel_l2(m.inverse(y.to(dev)), fs(y, hk)) < TOL_OP

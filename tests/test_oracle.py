@@ -341,3 +341,29 @@ def test_oracle_rvq_matches_reference_golden(golden_dir, tag):
     sd1 = {"r." + k: v for k, v in g["sd1"].items()}
     qe, le, ie, _ = O.rvq_forward(g["z"], sd1, "r", c["num_quantizers"], training=False)
     assert torch.equal(ie, g["ind_eval"]) and rel_l2(qe, g["q_eval"]) < 1e-6 and float(le) == 0.0
+
+
+def test_oracle_noncached_pqmf_variants_match_reference():
+    """PQMF (polyphase / classic, rave/pqmf.py:92-242) restated; pinned to the reference classes when present and
+    to the documented relation with the cached bank: same analysis, synthesis advanced by one 16-sample frame."""
+    b = O.pqmf_buffers(100, 16)
+    hk = b["hk"]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 1, 4096, generator=g)
+    y = torch.randn(2, 16, 256, generator=g)
+    yc = O.pqmf_analysis(x, b["forward_conv.weight"])
+    for f in (O.pqmf_polyphase_forward, O.pqmf_classic_forward):
+        assert rel_l2(f(x, hk), yc) < 2e-6
+    xc = O.pqmf_synthesis(y, b["inverse_conv.weight"])
+    for f in (O.pqmf_polyphase_inverse, O.pqmf_classic_inverse):
+        out = f(y, hk)
+        assert out.shape == xc.shape
+        assert rel_l2(out[..., :-16], xc[..., 16:]) < 1e-5
+    import ref_import as REF
+    if REF.reference_available():
+        REF.import_reference()
+        from rave import pqmf as rp
+        for poly, fa, fs in ((True, O.pqmf_polyphase_forward, O.pqmf_polyphase_inverse),
+                             (False, O.pqmf_classic_forward, O.pqmf_classic_inverse)):
+            m = rp.PQMF(attenuation=100, n_band=16, polyphase=poly)
+            assert rel_l2(fa(x, hk), m(x)) < TOL and rel_l2(fs(y, hk), m.inverse(y)) < TOL
