@@ -260,6 +260,18 @@ int rh_vq_ema_update_f32(const float* x, const int64_t* indices, int64_t n_vecto
                          float decay, float epsilon, float* cluster_size, float* embed_avg, float* embed,
                          rh_stream_t stream);
 
+/* ---- training data feed (SURVEY.md section 8f "next" #4) --------------------------------------------- */
+
+/* One minibatch of the reference's per-item CPU chain (rave/dataset.py:75-78,218-229,246,283-299;
+ * rave/transforms.py:96-115) in one launch: for every row r (one channel of one clip)
+ *   x = float32(pcm[src_offset[r] + n]) / 32767                                   n < n_signal   (crop applied by the offset)
+ *   y = lfilter([b0,b1,b2], [1,a1,a2], x) in float64 (direct form II transposed)  if coef[r][0] is not NaN
+ *   out[r][n] = float32(y + noise[r][n] / 2^bit_depth)
+ * coef: rows x 5 doubles (b0, b1, b2, a1, a2), b0 = NaN skips the filter (RandomApply miss); noise: U[0,1) floats.
+ * The random draws (item, crop point, pole angle, noise) belong to the caller. */
+int rh_feed_batch_i16_f32(const int16_t* pcm, const int64_t* src_offset, const double* coef, const float* noise,
+                          int32_t rows, int32_t n_signal, int32_t bit_depth, float* out, rh_stream_t stream);
+
 /* ---- spectral distance ("next" item #1 of SURVEY.md section 8f, beside the hot path) ------------- */
 
 /* STFT framing of torchaudio.transforms.Spectrogram(center=True, pad_mode="reflect") as used by

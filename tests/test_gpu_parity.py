@@ -882,3 +882,32 @@ def test_noncached_pqmf_mirror_vs_oracle(dev, polyphase):
     fs = O.pqmf_polyphase_inverse if polyphase else O.pqmf_classic_inverse
     assert rel_l2(m(x.to(dev)), fa(x, hk)) < TOL_OP
     assert rel_l2(m.inverse(y.to(dev)), fs(y, hk)) < TOL_OP
+
+
+def test_gpu_batch_feed_matches_the_reference_transform_chain(dev):
+    """rave/dataset.py:75-78,218-229,246,283-299 + rave/transforms.py:96-115 on injected draws: int16 -> float32,
+    crop, all-pass phase mangle through scipy.signal.lfilter (float64), Dequantize(16), float32."""
+    import numpy as np
+    from scipy.signal import lfilter
+    from rave_amd import data as D
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-20000, 20000, size=(5, 2, 30000), dtype=np.int16)
+    feed = D.GpuBatchFeed(torch.from_numpy(pcm).to(dev), sr=44100, seed=1)
+    batch, n = 4, 8192
+    items = np.array([3, 0, 4, 3])
+    in_points = np.array([0, 123, 30000 - n, 777])
+    angles = [0.05, None, 0.2, 0.003]
+    noise = rng.random((batch * 2, n)).astype(np.float32)
+    got = feed.sample(batch, n, draws=(items, in_points, angles), noise=torch.from_numpy(noise)).cpu().numpy()
+    for b in range(batch):
+        x = pcm[items[b]].astype(np.float32) / (2 ** 15 - 1)
+        x = x[..., in_points[b]:in_points[b] + n]
+        if angles[b] is not None:
+            bb, aa = D.pole_to_z_filter(angles[b], .99)
+            x = lfilter(bb, aa, x)
+        x = x + noise[2 * b:2 * b + 2].astype(np.float64) / 2 ** 16
+        ref = x.astype(np.float32)
+        assert np.abs(got[b] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), b
+    # the feed's own draws: right shape, finite, inside the PCM range after the all-pass filter
+    y = feed.sample(3, 4096)
+    assert y.shape == (3, 2, 4096) and bool(torch.isfinite(y).all())
