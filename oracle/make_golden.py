@@ -343,6 +343,47 @@ def golden_rvq(name="rvq_tiny.pt"):
     print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
 
 
+def golden_v3_step_tiny(name="v3_step_tiny.pt"):
+    """BASELINE configs[4] shrunk (configs/v3.gin + causal.gin, stereo): ONE discriminator step and ONE generator step
+    of the reference's own ``training_step`` (rave/model.py:288-413) with the descript discriminator, from the same
+    initial weights.  The discriminator's 42.6 M weights come from rave_oracle.seeded_state_dict (seed stored); stored
+    are every logged loss and, for the discriminator step, the (subsampled) discriminator parameter gradients -- the
+    hinge loss is well conditioned, unlike the spectral-loss gradient of the generator step."""
+    cap, lat, n_signal, batch = 6, 8, 32768, 1
+    torch.manual_seed(0)
+    m = build_reference_rave("v3", n_channels=2, capacity=cap, latent_size=lat, causal=True)
+    m.train()
+    attach_optimizers(m)
+    dshapes = {k: tuple(v.shape) for k, v in m.discriminator.state_dict().items() if not k.endswith(".window")}
+    seed = 303
+    m.discriminator.load_state_dict(O.seeded_state_dict(dshapes, seed), strict=False)
+    init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen_sd = {k: t(v) for k, v in init.items() if k.startswith(("pqmf.", "encoder.", "decoder."))}
+    x = O.synthetic_batch(batch, 2, n_signal, seed=7)
+    with torch.no_grad():
+        zp = m.encode(x)
+        torch.manual_seed(1234)
+        z = m.encoder.reparametrize(zp)[0]
+        torch.manual_seed(1234)
+        eps = torch.randn(z.shape)
+    out = dict(config=dict(capacity=cap, latent_size=lat, n_signal=n_signal, batch=batch, n_channels=2, causal=True),
+               state_dict=gen_sd, disc_seed=seed, disc_shapes=dshapes, x=t(x), eps=eps, grad_step=257)
+    for idx, tag in ((0, "dis"), (1, "gen")):
+        m.load_state_dict(init)
+        attach_optimizers(m)
+        m.zero_grad(set_to_none=True)
+        m.warmed_up = True
+        torch.manual_seed(1234)
+        m.training_step(x.clone(), idx)
+        out[tag] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)})
+        if tag == "dis":
+            out[tag]["grads"] = {k: _subsample(p.grad) for k, p in m.discriminator.named_parameters()}
+        print(tag, {k: float(v) for k, v in out[tag]["losses"].items()})
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+    build_reference_rave("v2", capacity=cap, latent_size=lat, causal=False)     # reset the causal gin binding
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
@@ -353,3 +394,4 @@ if __name__ == "__main__":
     golden_v1_tiny()
     golden_disc2d()
     golden_rvq()
+    golden_v3_step_tiny()

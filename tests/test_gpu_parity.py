@@ -911,3 +911,43 @@ def test_gpu_batch_feed_matches_the_reference_transform_chain(dev):
     # the feed's own draws: right shape, finite, inside the PCM range after the all-pass filter
     y = feed.sample(3, 4096)
     assert y.shape == (3, 2, 4096) and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("tag,idx", [("dis", 0), ("gen", 1)])
+def test_v3_descript_training_step_golden(golden_dir, dev, tag, idx):
+    """BASELINE configs[4] shrunk (v3.gin + causal.gin, stereo, descript discriminator): every loss the reference's
+    own training_step logs, and -- on the discriminator step -- its discriminator parameter gradients."""
+    from rave_amd import model as M
+    g = _load(golden_dir, "v3_step_tiny.pt")
+    c = g["config"]
+    m = M.build_v3(n_channels=c["n_channels"], causal=c["causal"], capacity=c["capacity"], latent_size=c["latent_size"])
+    dsd = O.seeded_state_dict(g["disc_shapes"], g["disc_seed"])
+    assert {k: tuple(v.shape) for k, v in m.discriminator.state_dict().items() if not k.endswith(".window")} == g["disc_shapes"]
+    sd = dict(g["state_dict"])
+    sd.update({"discriminator." + k: v for k, v in dsd.items()})
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith((".window", "receptive_field")) for k in res.missing_keys), res
+    m.to(dev).train()
+    m.configure_optimizers()
+    m.warmed_up = True
+    before = {k: v.detach().clone() for k, v in m.discriminator.named_parameters()}
+    logged = m.training_step(g["x"].to(dev), idx, eps=g["eps"].to(dev))
+    ref = g[tag]["losses"]
+    for k in ("multiband_spectral_distance", "fullband_spectral_distance", "regularization", "feature_matching",
+              "adversarial", "loss_dis"):
+        got, want = float(logged[k].detach()), float(ref[k])
+        assert abs(got - want) <= 2e-4 * max(1.0, abs(want)), (k, got, want)
+    if tag == "dis":
+        bad = []
+        for k, p in m.discriminator.named_parameters():
+            got = p.grad.reshape(-1)
+            got = got if got.numel() <= 200_000 else got[::g["grad_step"]]
+            want = g[tag]["grads"][k]
+            # the hinge loss puts -1/N on every real and +1/N on every fake score: the last conv's bias gradient
+            # cancels to rounding noise (|g| ~ 2e-6) in the reference too -- compared in absolute terms
+            err = float((got.detach().double().cpu() - want.double()).norm())
+            if err > 5e-4 * float(want.double().norm()) + 1e-5:
+                bad.append((k, err, float(want.double().norm())))
+        assert not bad, bad[:5]
+        # Adam moved the discriminator (and only it)
+        assert any(not torch.equal(before[k], p.detach()) for k, p in m.discriminator.named_parameters())
