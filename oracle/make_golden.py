@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.dont_write_bytecode = True
 
-from ref_models import attach_optimizers, build_reference_rave  # noqa: E402
+from ref_models import attach_optimizers, build_reference_discrete, build_reference_rave  # noqa: E402
 import rave_oracle as O  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
@@ -384,6 +384,59 @@ def golden_v3_step_tiny(name="v3_step_tiny.pt"):
     build_reference_rave("v2", capacity=cap, latent_size=lat, causal=False)     # reset the causal gin binding
 
 
+def golden_discrete_step_tiny(name="discrete_step_tiny.pt"):
+    """BASELINE configs[3] shrunk (configs/discrete.gin + spectral_discriminator.gin, RVQ ENABLED as the benchmark
+    does): k-means init + one warm-up pass by the reference, then ONE discriminator step and ONE generator step of its
+    own ``training_step`` from the same state: every logged loss, the noise-augmentation draw (captured from
+    torch.randn), the EMA-updated codebooks, and the discriminator gradients of the discriminator step."""
+    cfg = dict(capacity=6, latent_size=8, noise_augmentation=4, num_quantizers=3, codebook_size=16, spectral_capacity=4)
+    n_signal, batch = 32768, 2
+    torch.manual_seed(0)
+    m = build_reference_discrete(**cfg)
+    m.train()
+    attach_optimizers(m)
+    m.encoder.enabled.fill_(1)
+    x = O.synthetic_batch(batch, 1, n_signal, seed=11)
+    with torch.no_grad():
+        # default-initialised encoders emit |z| ~ 1e-3, which makes the commitment loss ~1e-8: raise the gain of the
+        # head conv so that the quantiser works on O(1) latents
+        head = [mod for mod in m.encoder.encoder.net if hasattr(mod, "weight_g")][-1]
+        head.weight_g.mul_(300.0)
+    with torch.no_grad():                       # k-means initialisation of every codebook + first EMA pass
+        m.encoder.reparametrize(m.encode(x))
+    init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = dict(config=dict(cfg, n_signal=n_signal, batch=batch), state_dict={k: t(v) for k, v in init.items()}, x=t(x),
+               grad_step=257)
+    real_randn = torch.randn
+    for idx, tag in ((0, "dis"), (1, "gen")):
+        m.load_state_dict(init)
+        attach_optimizers(m)
+        m.zero_grad(set_to_none=True)
+        m.warmed_up = True
+        draws = []
+
+        def spy(*a, **k):
+            r = real_randn(*a, **k)
+            draws.append(r.clone())
+            return r
+
+        torch.manual_seed(1234)
+        torch.randn = spy
+        try:
+            m.training_step(x.clone(), idx)
+        finally:
+            torch.randn = real_randn
+        noise = [d for d in draws if d.dim() == 3 and d.shape[1] == cfg["noise_augmentation"]]
+        assert len(noise) == 1, [tuple(d.shape) for d in draws]
+        out[tag] = dict(losses={k: t(v) for k, v in m.logged.items() if torch.is_tensor(v)}, noise=noise[0],
+                        codebooks={k: t(v) for k, v in m.state_dict().items() if "_codebook" in k})
+        if tag == "dis":
+            out[tag]["grads"] = {k: _subsample(p.grad) for k, p in m.discriminator.named_parameters()}
+        print(tag, {k: round(float(v), 5) for k, v in out[tag]["losses"].items()})
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
@@ -395,3 +448,4 @@ if __name__ == "__main__":
     golden_disc2d()
     golden_rvq()
     golden_v3_step_tiny()
+    golden_discrete_step_tiny()

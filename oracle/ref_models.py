@@ -134,3 +134,40 @@ def attach_optimizers(model):
     model._opts = (gen["optimizer"], dis["optimizer"])
     model._scheds = gen["lr_scheduler"]["scheduler"]
     return model
+
+
+def build_reference_discrete(capacity=96, latent_size=128, noise_augmentation=128, num_quantizers=16, codebook_size=1024,
+                             spectral_capacity=32, n_channels=1, n_band=16, sampling_rate=44100):
+    """Reference ``rave.RAVE`` for configs/discrete.gin + configs/spectral_discriminator.gin (BASELINE configs[3]):
+    RATIOS [4,4,2,2] (discrete.gin:14), EncoderV2(n_out=1) inside DiscreteEncoder with a ResidualVectorQuantization
+    bottleneck and noise channels (discrete.gin:24-40), generator latent = latent + noise (v2.gin:24-26,47),
+    log_epsilon = 1 (discrete.gin:22), num_skipped_features = 0 (discrete.gin:48), discriminators =
+    [MultiScaleDiscriminator, MultiScaleSpectralDiscriminator] (spectral_discriminator.gin:6-17)."""
+    rave = import_reference()
+    from rave import blocks, core, discriminator, pqmf, quantization
+    set_causal(False)
+    ratios = [4, 4, 2, 2]
+    enc = partial(blocks.DiscreteEncoder,
+                  encoder_cls=partial(blocks.EncoderV2, data_size=n_band, capacity=capacity, ratios=ratios,
+                                      latent_size=latent_size, n_out=1, kernel_size=3, dilations=V2_DILATIONS),
+                  vq_cls=partial(quantization.ResidualVectorQuantization, num_quantizers=num_quantizers, dim=latent_size,
+                                 codebook_size=codebook_size),
+                  num_quantizers=num_quantizers, noise_augmentation=noise_augmentation)
+    dec = partial(blocks.GeneratorV2, data_size=n_band, capacity=capacity, ratios=ratios,
+                  latent_size=latent_size + noise_augmentation, kernel_size=3, dilations=V2_DILATIONS,
+                  amplitude_modulation=True)
+    msd = partial(discriminator.MultiScaleDiscriminator, n_discriminators=3,
+                  convnet=partial(discriminator.ConvNet, out_size=1, capacity=capacity, n_layers=4, stride=4,
+                                  conv=nn.Conv1d, kernel_size=15))
+    mssd = partial(discriminator.MultiScaleSpectralDiscriminator, scales=[4096, 2048, 1024, 512, 256],
+                   convnet=partial(discriminator.EncodecConvNet, capacity=spectral_capacity))
+    disc = partial(discriminator.CombineDiscriminators, discriminators=[msd, mssd])
+    stft = partial(core.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128], sample_rate=sampling_rate, magnitude=True)
+    dist = partial(core.AudioDistanceV1, multiscale_stft=stft, log_epsilon=1)
+    return rave.RAVE(latent_size=latent_size, sampling_rate=sampling_rate,
+                     pqmf=partial(pqmf.CachedPQMF, attenuation=100, n_band=n_band), encoder=enc, decoder=dec,
+                     discriminator=disc, phase_1_duration=200000, gan_loss=core.hinge_gan, valid_signal_crop=True,
+                     feature_matching_fun=partial(core.mean_difference, norm="L1", relative=True),
+                     num_skipped_features=0, audio_distance=dist, multiband_audio_distance=dist,
+                     weights={"feature_matching": 20}, update_discriminator_every=4, n_channels=n_channels,
+                     n_bands=n_band)

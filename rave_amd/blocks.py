@@ -467,6 +467,9 @@ class DiscreteEncoder(nn.Module):
         self.noise_augmentation = noise_augmentation
 
     def reparametrize(self, z, eps=None, noise: Optional[torch.Tensor] = None):
+        """``eps`` / ``noise``: inject the noise-augmentation draw (parity runs); the step passes it as ``eps``."""
+        if noise is None:
+            noise = eps
         if self.enabled:
             if self.rvq is None:
                 raise RuntimeError("rave_amd DiscreteEncoder: enabled but constructed without vq_cls")

@@ -951,3 +951,42 @@ def test_v3_descript_training_step_golden(golden_dir, dev, tag, idx):
         assert not bad, bad[:5]
         # Adam moved the discriminator (and only it)
         assert any(not torch.equal(before[k], p.detach()) for k, p in m.discriminator.named_parameters())
+
+
+@pytest.mark.parametrize("tag,idx", [("dis", 0), ("gen", 1)])
+def test_discrete_spectral_training_step_golden(golden_dir, dev, tag, idx):
+    """BASELINE configs[3] shrunk (discrete.gin + spectral_discriminator.gin, RVQ enabled): every loss the reference's
+    own training_step logs, the EMA-updated codebooks it leaves behind and -- on the discriminator step -- the
+    discriminator parameter gradients (MSD + Encodec STFT nets)."""
+    from rave_amd import model as M
+    g = _load(golden_dir, "discrete_step_tiny.pt")
+    c = dict(g["config"])
+    n_signal, batch = c.pop("n_signal"), c.pop("batch")
+    m = M.build_discrete(**c)
+    # the reference model also carries export-time analysis buffers (latent_pca, latent_mean, fidelity)
+    sd = {k: v for k, v in g["state_dict"].items() if k.startswith(("pqmf.", "encoder.", "decoder.", "discriminator."))}
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k == "receptive_field" for k in res.missing_keys), res
+    assert int(m.encoder.enabled) == 1
+    m.to(dev).train()
+    m.configure_optimizers()
+    m.warmed_up = True
+    logged = m.training_step(g["x"].to(dev), idx, eps=g[tag]["noise"].to(dev))
+    ref = g[tag]["losses"]
+    for k in ("multiband_spectral_distance", "fullband_spectral_distance", "regularization", "feature_matching",
+              "adversarial", "loss_dis"):
+        got, want = float(logged[k].detach()), float(ref[k])
+        assert abs(got - want) <= 2e-4 * max(1.0, abs(want)) if k != "regularization" else abs(got - want) <= 1e-4 * abs(want), \
+            (k, got, want)
+    for k, want in g[tag]["codebooks"].items():
+        assert rel_l2(m.state_dict()[k].float(), want.float()) < TOL_OP, k
+    if tag == "dis":
+        bad = []
+        for k, p in m.discriminator.named_parameters():
+            got = p.grad.reshape(-1)
+            got = got if got.numel() <= 200_000 else got[::g["grad_step"]]
+            want = g[tag]["grads"][k]
+            err = float((got.detach().double().cpu() - want.double()).norm())
+            if err > 5e-4 * float(want.double().norm()) + 1e-5:
+                bad.append((k, err, float(want.double().norm())))
+        assert not bad, bad[:5]
