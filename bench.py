@@ -204,7 +204,7 @@ def main():
             a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
         # forward and data-gradient launches are the SAME kernel (conv_igemm_dma_kernel): group them
-        kernels = {"conv_igemm_dma_kernel (forward + data-gradient launches)": ["conv_fwd", "conv_dgrad"],
+        kernels = {"conv_x6_kernel + conv_igemm_dma_kernel (forward + data-gradient launches)": ["conv_fwd", "conv_dgrad"],
                    "wgrad_dma_kernel (weight-gradient launches)": ["conv_wgrad"]}
         ksum = {k: [sum(agg[f][i] for f in fams if f in agg) for i in range(4)] for k, fams in kernels.items()}
         dom_name = max(ksum, key=lambda k: ksum[k][3])
@@ -229,8 +229,11 @@ def main():
             "algorithmic_bytes_per_launch": by / n, "traffic_note": traffic_note,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9,
-            "note": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32); HIP events on the launch stream around "
-                    "every launch of the kernel family with the largest total time",
+            "note": "f32 in / f32 accumulate; the stride-1 convolutions run conv_x6_kernel (every f32 split exactly into "
+                    "3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block: same numerics class, ceiling 2.5 PF / 6 = "
+                    "417 TFLOP/s f32-equivalent), the strided / transposed ones conv_igemm_dma_kernel "
+                    "(v_mfma_f32_32x32x2_f32, ceiling 157.3); peak = the exact-f32 MFMA peak; HIP events on the launch "
+                    "stream around every launch of the kernel family with the largest total time",
         }
         out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,

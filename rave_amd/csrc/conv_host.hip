@@ -140,26 +140,74 @@ void plan_to_params(const TapPlan& t, ConvP* p) {
     for (int i = 0; i < t.nslots; ++i) p->off[i] = t.off[i];
 }
 
-__device__ __forceinline__ void pack_one_elem(const PackP& p, long e) {
-    const int m = (int)(e % p.Mp);
-    const long r = e / p.Mp;
-    const int c = (int)(r % p.C);
-    const int slot = (int)(r / p.C);
-    float v = 0.f;
-    if (m < p.M) {
-        const long src = p.m_major ? ((long)m * p.C + c) * p.k + p.kk[slot]
-                                   : ((long)c * p.M + m) * p.k + p.kk[slot];
-        v = p.w[src];
-        if (p.scale) v *= p.scale[p.m_major ? m : c];   // dim 0 of the PyTorch weight tensor
+// One 32 (m) x 32 (c) tile of one slot of one packed copy per workgroup, through LDS: the source is read along its
+// contiguous index ((m*C + c)*k + kk is contiguous-ish in c for the m-major copies, in m for the others), the packed
+// f32 tensor is written along m, and -- for layers the bf16x6 kernels can take (conv_x6.hip) -- the same tile is
+// split exactly into three bf16 pieces and written as 16-byte fragments of 8 channels ([slot][C/8][3][Mp][8]).
+__device__ __forceinline__ void split3_bits(float x, unsigned& a, unsigned& b, unsigned& c) {
+    a = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(a);
+    b = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b);
+    c = __float_as_uint(r2) & 0xffff0000u;
+}
+
+__host__ __device__ __forceinline__ long pack_tiles(const PackP& q) {
+    return q.total ? (q.total / ((long)q.C * q.Mp)) * (q.Mp / 32) * ((q.C + 31) / 32) : 0;
+}
+
+__device__ __forceinline__ void pack_tile(const PackP& q, long tile, float (*lds)[33]) {
+    const int ct = (q.C + 31) / 32, mt = q.Mp / 32;
+    const int c0 = (int)(tile % ct) * 32;
+    tile /= ct;
+    const int m0 = (int)(tile % mt) * 32;
+    const int slot = (int)(tile / mt);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const int kk = q.kk[slot];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                               // lds[c][m]
+        int m, c;
+        if (q.m_major) { m = m0 + ty + 8 * i; c = c0 + tx; }
+        else { c = c0 + ty + 8 * i; m = m0 + tx; }
+        float v = 0.f;
+        if (m < q.M && c < q.C) {
+            v = q.m_major ? q.w[((long)m * q.C + c) * q.k + kk] : q.w[((long)c * q.M + m) * q.k + kk];
+            if (q.scale) v *= q.scale[q.m_major ? m : c];       // dim 0 of the PyTorch weight tensor
+        }
+        lds[c - c0][m - m0] = v;
     }
-    p.wp[e] = v;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, m = m0 + tx;
+        if (c < q.C) q.wp[((long)slot * q.C + c) * q.Mp + m] = lds[ty + 8 * i][tx];
+    }
+    if (q.wq && threadIdx.x < 128) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int cb = threadIdx.x >> 5, m = threadIdx.x & 31;
+        if (c0 + cb * 8 < q.C) {
+            unsigned h[3][8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) split3_bits(lds[cb * 8 + k][m], h[0][k], h[1][k], h[2][k]);
+            u32x4* dst = reinterpret_cast<u32x4*>(q.wq) + (((long)slot * (q.C >> 3) + (c0 >> 3) + cb) * 3) * q.Mp + m0 + m;
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                u32x4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
+                dst[(long)s3 * q.Mp] = pk;
+            }
+        }
+    }
 }
 
 // Both packed copies in one launch (forward operand, then data-gradient operand).
 __global__ __launch_bounds__(256) void pack_kernel(const PackP a, const PackP b) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < a.total) pack_one_elem(a, e);
-    else if (e - a.total < b.total) pack_one_elem(b, e - a.total);
+    __shared__ float lds[32][33];
+    const long t = blockIdx.x;
+    const long na = pack_tiles(a);
+    if (t < na) pack_tile(a, t, lds);
+    else if (t - na < pack_tiles(b)) pack_tile(b, t - na, lds);
 }
 
 int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* scale, float* wp, PackP* p) {
@@ -174,6 +222,8 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
     p->m_major = t.src_m_major ? 1 : 0;
     p->total = (long)t.nslots * t.C * p->Mp;
     for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
+    if (rh_x6_weights(t.M, t.C, t.nslots, t.nphase, t.is, t.os, d->inner) && !d->transposed)
+        p->wq = reinterpret_cast<unsigned short*>(wp + p->total);      // 16-byte aligned: Mp % 32 == 0
     return RH_OK;
 }
 
@@ -182,18 +232,18 @@ int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float
     PackP a, b;
     if (int e = fill_pack(d, 0, w, scale, wp_fwd, &a)) return e;
     if (int e = fill_pack(d, 1, w, scale, wp_bwd, &b)) return e;
-    const long total = a.total + b.total;
-    if (total == 0) return RH_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, a, b);
+    const long tiles = pack_tiles(a) + pack_tiles(b);
+    if (tiles == 0) return RH_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a, b);
     return rh_check_launch("conv1d_pack");
 }
 
 }  // namespace
 
 int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what) {
-    const long total = a.total + b.total;
-    if (total == 0) return RH_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, a, b);
+    const long tiles = pack_tiles(a) + pack_tiles(b);
+    if (tiles == 0) return RH_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a, b);
     return rh_check_launch(what);
 }
 
@@ -216,6 +266,7 @@ int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p) {
     p->epi_slope = 0.f;
     p->out_act = d->out_act;
     p->out_slope = d->out_slope;
+    p->x6_packed = !d->transposed;
     return RH_OK;
 }
 
@@ -238,6 +289,7 @@ int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p) {
     p->epi_slope = d->act_slope;
     p->out_act = RH_ACT_NONE;      // the caller pre-multiplies dy by out_act'(y) (rh_act_bwd_f32)
     p->out_slope = 0.f;
+    p->x6_packed = !d->transposed;
     return RH_OK;
 }
 
@@ -245,7 +297,12 @@ extern "C" int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which) {
     if (validate(d)) return -1;
     const int64_t M = which == 0 ? d->c_out : d->c_in;
     const int64_t C = which == 0 ? d->c_in : d->c_out;
-    return (int64_t)d->kernel * C * round32((int)M);
+    const int64_t n32 = (int64_t)d->kernel * C * round32((int)M);
+    TapPlan t;
+    if (build_plan(d, which, &t)) return -1;
+    // + the bf16x6 section (3 x 2 bytes per weight) for the layers conv_x6.hip can take
+    if (rh_x6_weights(t.M, t.C, t.nslots, t.nphase, t.is, t.os, d->inner) && !d->transposed) return n32 + n32 + n32 / 2;
+    return n32;
 }
 
 extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd,
@@ -299,55 +356,6 @@ __global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __rest
         const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
         p.norms[r] = norm;
         p.scale[r] = p.g[r] / norm;
-    }
-}
-
-// One 32 (m) x 32 (c) tile of one slot of one packed copy per workgroup.  The m-major copies (source index
-// (m*C + c)*k + kk: consecutive m are C*k floats apart) go through an LDS transpose so that the source is read
-// along c and the packed tensor written along m; the element-per-thread version read one 64-byte sector per
-// float there (0.42 ms per v2 step for 0.4 GB of useful traffic).
-__device__ __forceinline__ long pack_tiles(const PackP& q) {
-    return q.total ? (q.total / ((long)q.C * q.Mp)) * (q.Mp / 32) * ((q.C + 31) / 32) : 0;
-}
-
-__device__ __forceinline__ void pack_tile(const PackP& q, long tile, float (*lds)[33]) {
-    const int ct = (q.C + 31) / 32, mt = q.Mp / 32;
-    const int c0 = (int)(tile % ct) * 32;
-    tile /= ct;
-    const int m0 = (int)(tile % mt) * 32;
-    const int slot = (int)(tile / mt);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
-    const int kk = q.kk[slot];
-    if (q.m_major) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                           // read: rows m, fast index c
-            const int m = m0 + ty + 8 * i, c = c0 + tx;
-            float v = 0.f;
-            if (m < q.M && c < q.C) {
-                v = q.w[((long)m * q.C + c) * q.k + kk];
-                if (q.scale) v *= q.scale[m];
-            }
-            lds[ty + 8 * i][tx] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                           // write: rows c, fast index m
-            const int c = c0 + ty + 8 * i, m = m0 + tx;
-            if (c < q.C) q.wp[((long)slot * q.C + c) * q.Mp + m] = lds[tx][ty + 8 * i];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = c0 + ty + 8 * i, m = m0 + tx;
-            if (c < q.C) {
-                float v = 0.f;
-                if (m < q.M) {
-                    v = q.w[((long)c * q.M + m) * q.k + kk];
-                    if (q.scale) v *= q.scale[c];
-                }
-                q.wp[((long)slot * q.C + c) * q.Mp + m] = v;
-            }
-        }
     }
 }
 

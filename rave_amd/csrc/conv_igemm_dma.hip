@@ -486,8 +486,19 @@ bool rh_conv_dma_eligible(const ConvP& p) {
     return in_b < 0x7fffffffull && w_b < 0x7fffffffull && row_span < 0x7fffffffull;
 }
 
+int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream) {
+    const long total = (long)p.B * p.M * p.out_valid;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, p, total);
+    return rh_check_launch("conv_splitk_finalize");
+}
+
 int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes) {
     fill_sizes(p);
+    {   // stride-1 convolutions of the residual units: exact f32 on the bf16 matrix cores (conv_x6.hip)
+        bool used = false;
+        if (int e = rh_conv_launch_x6(p, stream, what, ws, ws_bytes, &used)) return e;
+        if (used) return RH_OK;
+    }
     if (p.M <= 32) return launch_dma<1, 2, 1, 4>(p, stream, what, ws, ws_bytes);
     if (p.M <= 64) return launch_dma<2, 1, 1, 4>(p, stream, what, ws, ws_bytes);
     if (p.M % 96 == 0 || p.M < 96) return launch_dma<3, 1, 1, 4>(p, stream, what, ws, ws_bytes);
@@ -498,9 +509,10 @@ int64_t rh_conv_splitk_workspace(ConvP p) {
     if (p.B <= 0 || p.ncols <= 0 || p.M <= 0 || !rh_conv_dma_eligible(p)) return 0;
     fill_sizes(p);
     int64_t want = 0;
+    const int64_t x6 = rh_conv_x6_workspace(p);
     if (p.M <= 32) launch_dma<1, 2, 1, 4>(p, nullptr, "", nullptr, 0, true, &want);
     else if (p.M <= 64) launch_dma<2, 1, 1, 4>(p, nullptr, "", nullptr, 0, true, &want);
     else if (p.M % 96 == 0 || p.M < 96) launch_dma<3, 1, 1, 4>(p, nullptr, "", nullptr, 0, true, &want);
     else launch_dma<2, 2, 2, 2>(p, nullptr, "", nullptr, 0, true, &want);
-    return want;
+    return want > x6 ? want : x6;
 }

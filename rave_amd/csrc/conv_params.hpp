@@ -38,6 +38,11 @@ struct ConvP {
     float* part;                               // [ksplit][B][M][out_row] scratch (caller workspace)
     long part_stride;                          // B*M*out_row
     unsigned in_bytes, w_bytes;                // buffer sizes for the bounds-checked DMA descriptors
+    // --- bf16x6 path (conv_x6.hip) only ---
+    const unsigned short* wq;                  // pre-split weights [slot][C/8][3][Mp][8] bf16 (caller scratch)
+    unsigned wq_bytes;
+    int x6_xf_floats, x6_xb_bytes, x6_w_bytes; // LDS regions: f32 input stage, bf16 tile, one weight stage
+    int x6_packed;                             // the packed operand carries the bf16x6 section (rh_conv1d_* packers)
     int nphase;
     int ph_oph[kMaxPhases], ph_ntaps[kMaxPhases], ph_tap0[kMaxPhases], ph_minoff[kMaxPhases],
         ph_maxoff[kMaxPhases];
@@ -80,6 +85,7 @@ struct PackP {
     const float* w;
     const float* scale;   // per dim-0 slice (weight-norm g/||v||) or null
     float* wp;
+    unsigned short* wq;   // bf16x6 section [slot][C/8][3][Mp][8] behind the f32 section (conv_x6.hip) or null
     long total;           // nslots * C * Mp   (0 = nothing to do)
     int C, M, Mp, k;      // k = taps per (m, c) pair in the source tensor
     int m_major;          // source index = (m*C + c)*k + kk, else (c*M + m)*k + kk
@@ -100,3 +106,9 @@ int rh_conv_launch_sync(ConvP& p, hipStream_t stream, const char* what);   // re
 int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes);
 bool rh_conv_dma_eligible(const ConvP& p);
 int64_t rh_conv_splitk_workspace(ConvP p);     // bytes of scratch the launch would like (0 = none)
+int64_t rh_conv_x6_workspace(ConvP p);         // bf16x6 path: scratch it needs, -1 = geometry not eligible
+// weights eligible for the bf16x6 kernels (decided from the geometry alone, so that packers and launchers agree)
+inline bool rh_x6_weights(int M, int C, int ntaps, int nphase, int is, int os, int inner) {
+    return nphase == 1 && is == 1 && os == 1 && inner == 1 && ntaps >= 1 && ntaps <= 3 && (C & 15) == 0 && M % 96 == 0;
+}
+int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool* used);

@@ -148,6 +148,11 @@ CONV_CASES = [
     (4, 96, 1, 64, 1, 1, 1, (0, 0), 1, True, False),        # MSD last layer (Cout = 1)
     (1, 130, 70, 33, 5, 1, 2, (4, 4), 0, False, False),     # odd sizes everywhere
     (2, 32, 32, 5, 3, 1, 1, (1, 1), 2, False, False),       # snake, sequence shorter than a tile
+    # stride-1, C % 16 == 0, M % 96 == 0, rows % 4 == 0: the bf16x6 kernels (conv_x6.hip), forward and data gradient
+    (2, 96, 96, 256, 3, 1, 9, (9, 9), 1, False, False),     # dilated k3 of a residual unit
+    (3, 192, 96, 64, 3, 1, 3, (6, 0), 1, True, True),       # causal pad, batch folded, bias + residual
+    (2, 96, 192, 1024, 1, 1, 1, (0, 0), 0, False, False),   # pointwise, no activation
+    (9, 384, 768, 32, 3, 1, 1, (1, 1), 1, False, False),    # many channels on a short sequence: split-K over 16-channel chunks
 ]
 
 

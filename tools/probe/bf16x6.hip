@@ -165,3 +165,145 @@ extern "C" int gemm(const float* x, const uint16_t* wq, float* out, int T, int C
     hipLaunchKernelGGL(gemm_bf16x6_kernel<TM>, grid, dim3(256), lds, (hipStream_t)s, x, wq, out, T, C, M, N, NX, mode);
     return (int)hipGetLastError();
 }
+
+// ---- v2: 2 workgroups per CU (77 KB LDS: single f32 stage, single bf16 tile, double-buffered weights), per-lane DMA
+// offsets computed once, conversion placed between the DMA wait and the next DMA issue, MFMAs interleaved over tm.
+template <int TM>
+__global__ __launch_bounds__(256) void gemm_bf16x6_v2_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wq,
+                                                             float* __restrict__ out, int T, int C, int M, int N, int NX,
+                                                             int mode) {
+    constexpr int BM = TM * 32, BN = 128;
+    constexpr int kNW = 8, kNXI = 3;             // DMA slots per lane: weights (T <= 3), x tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int P = BN + T - 1;
+    const int pitch = (P + 3) & ~3;
+    const int xf_floats = (16 * pitch + 255) & ~255;
+    const int xb_bytes = 2 * 3 * P * 16;
+    const int w16 = T * 2 * 3 * BM;
+    const int w_bytes = ((w16 + 63) & ~63) * 16;
+    float* xf = reinterpret_cast<float*>(smem_raw);
+    unsigned char* xb = smem_raw + xf_floats * 4;
+    unsigned char* ws = xb + ((xb_bytes + 15) & ~15);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)((long)C * NX * 4), 0x00020000);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wq), 0, (unsigned)((long)T * C * M * 6), 0x00020000);
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+
+    // per-lane DMA source offsets at chunk 0; a chunk adds a scalar
+    unsigned wo[kNW], xo[kNXI];
+    const int nwi = (w16 + 255) / 256, x4 = 16 * (pitch / 4), nxi = (x4 + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < kNW; ++i) {
+        const int f = (wave + 4 * i) * 64 + lane;
+        const int m = f % BM;
+        int r = f / BM;
+        const int s3 = r % 3; r /= 3;
+        const int cb = r % 2, t = r / 2;
+        wo[i] = (i < nwi && f < w16) ? (unsigned)(((((long)t * (C / 8) + cb) * 3 + s3) * M + m0 + m) * 16) : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < kNXI; ++i) {
+        const int f = (wave + 4 * i) * 64 + lane;
+        const int c = f / (pitch / 4), v = f - c * (pitch / 4);
+        xo[i] = (i < nxi && f < x4 && n0 + 4 * v < NX) ? (unsigned)((((long)c) * NX + n0 + 4 * v) * 4) : kOOB;
+    }
+    const unsigned w_step = (unsigned)(2l * 3 * M * 16), x_step = (unsigned)(16l * NX * 4);
+    auto issue_w = [&](int ch, int stage) {
+#pragma unroll
+        for (int i = 0; i < kNW; ++i)
+            if (i < nwi && (wave + 4 * i) * 64 < w16) {
+                const unsigned off = wo[i] == kOOB ? kOOB : wo[i] + ch * w_step;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(ws + stage * w_bytes + (wave + 4 * i) * 1024), 16, off, 0, 0, 0);
+            }
+    };
+    auto issue_x = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < kNXI; ++i)
+            if (i < nxi && (wave + 4 * i) * 256 < xf_floats) {
+                const unsigned off = xo[i] == kOOB ? kOOB : xo[i] + ch * x_step;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(xf + (wave + 4 * i) * 256), 16, off, 0, 0, 0);
+            }
+    };
+
+    const int nchunks = C / 16;
+    const int g = lane >> 5, j = lane & 31;
+    issue_w(0, 0);
+    issue_x(0);
+    for (int i = 0; i < nchunks; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // A: chunk i landed; everyone finished the MFMAs of chunk i-1
+        for (int e = tid; e < 2 * P && !((mode & 1) && i > 0); e += 256) {
+            const int cb = e / P, pos = e - cb * P;
+            unsigned h[3][8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) split3(xf[(cb * 8 + k) * pitch + pos], h[0][k], h[1][k], h[2][k]);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                u32x4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
+                *reinterpret_cast<u32x4*>(xb + ((cb * 3 + s3) * P + pos) * 16) = pk;
+            }
+        }
+        __syncthreads();                                   // B: bf16 tile ready; the f32 stage is free again
+        if (i + 1 < nchunks && !((mode & 2) && i > 0)) {
+            issue_w(i + 1, (i + 1) & 1);
+            issue_x(i + 1);
+        }
+        const unsigned char* wl = ws + (i & 1) * w_bytes;
+        for (int t = 0; t < T && !(mode & 4); ++t) {
+            bf16x8 bfr[3], afr[TM][3];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+                bfr[s3] = *reinterpret_cast<const bf16x8*>(xb + ((g * 3 + s3) * P + wave * 32 + j + t) * 16);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+                    afr[tm][s3] = *reinterpret_cast<const bf16x8*>(wl + (((t * 2 + g) * 3 + s3) * BM + tm * 32 + j) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[SB[q]], acc[tm], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int kh = lane >> 5;
+    const int n = n0 + wave * 32 + j;
+    if (n < N) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < M) out[(long)m * N + n] = acc[tm][r];
+            }
+    }
+}
+
+extern "C" int gemm_v2(const float* x, const uint16_t* wq, float* out, int T, int C, int M, int N, int NX, void* s, int mode) {
+    constexpr int TM = 3;
+    if (T > 3) return -2;
+    const int P = 128 + T - 1, pitch = (P + 3) & ~3;
+    const int w16 = T * 2 * 3 * TM * 32;
+    const size_t lds = ((16 * pitch + 255) & ~255) * 4 + ((2 * 3 * P * 16 + 15) & ~15) + 2 * (size_t)((w16 + 63) & ~63) * 16;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x6_v2_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    if (lds > 160 * 1024) return -1;
+    dim3 grid((N + 127) / 128, (M + TM * 32 - 1) / (TM * 32));
+    hipLaunchKernelGGL(gemm_bf16x6_v2_kernel<TM>, grid, dim3(256), lds, (hipStream_t)s, x, wq, out, T, C, M, N, NX, mode);
+    return (int)hipGetLastError();
+}

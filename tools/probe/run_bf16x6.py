@@ -35,3 +35,20 @@ for (T, Cc, M, N) in [(1, 96, 96, 131072), (3, 96, 96, 131072), (3, 384, 384, 81
         res.append((mode, e0.elapsed_time(e1) / 10))
     print(f"T={T} C={Cc} M={M} N={N}: rel err vs f64 {err:.2e} (torch f32 matmul {err32:.2e}); " +
           ", ".join(f"mode{m}: {ms*1e3:.0f}us" for m, ms in res) + f" -> {fl/res[0][1]/1e9:.1f} TF/s")
+    out2 = torch.empty(M, N, device=dev)
+    rc = lib.gemm_v2(P(x.data_ptr()), P(wq.data_ptr()), P(out2.data_ptr()), T, Cc, M, N, NX, P(s), 0)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    err2 = float((out2.double() - ref).norm() / ref.norm())
+    res2 = []
+    for mode in (0, 1, 2, 3, 4, 7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            lib.gemm_v2(P(x.data_ptr()), P(wq.data_ptr()), P(out2.data_ptr()), T, Cc, M, N, NX, P(s), mode)
+        e0.record()
+        for _ in range(10):
+            lib.gemm_v2(P(x.data_ptr()), P(wq.data_ptr()), P(out2.data_ptr()), T, Cc, M, N, NX, P(s), mode)
+        e1.record()
+        torch.cuda.synchronize()
+        res2.append((mode, e0.elapsed_time(e1) / 10))
+    print(f"   v2: rel err {err2:.2e}; " + ", ".join(f"mode{m}: {ms*1e3:.0f}us" for m, ms in res2) + f" -> {fl/res2[0][1]/1e9:.1f} TF/s")
