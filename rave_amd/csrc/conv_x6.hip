@@ -115,25 +115,36 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(const ConvP p) {
     const int total_chunks = p.C >> 4;
     const int chunk0 = zsl * p.chunks_per_split;
     const int nchunks = min(p.chunks_per_split, total_chunks - chunk0);
+    // conversion work list of this thread: fragment (item, channel block, position) -> source / destination offsets
+    // and validity are chunk-invariant, computed once (nfrag <= 3 x 256)
+    constexpr int kNF = 3;
     const int nfrag = p.nb * 2 * pitch;
+    int fsrc[kNF], fdst[kNF];
+#pragma unroll
+    for (int q = 0; q < kNF; ++q) {
+        const int e = tid + 256 * q;
+        const int bl = e / (2 * pitch);
+        const int r = e - bl * 2 * pitch;
+        const int cb = r >= pitch ? 1 : 0;
+        const int pos = r - cb * pitch;
+        const int f = lo + pos;
+        const bool valid = f >= 0 && f < p.in_valid;
+        fsrc[q] = e < nfrag ? (valid ? (bl * 16 + cb * 8) * pitch + pos : -1) : -2;
+        fdst[q] = ((bl * 2 + cb) * 3) * pitch + pos;
+    }
     if (nchunks > 0) issue(chunk0, 0);
     for (int i = 0; i < nchunks; ++i) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // chunk i landed; every wave is done with the bf16 tile of chunk i-1
         // ---- convert: zero the positions outside the sequence (padding / neighbouring rows fetched by the
         //      16-byte DMA), fused LeakyReLU, exact 3-way bf16 split; one fragment = 8 channels of one position
-        for (int e = tid; e < nfrag; e += 256) {
-            const int bl = e / (2 * pitch);
-            const int r = e - bl * 2 * pitch;
-            const int cb = r >= pitch ? 1 : 0;
-            const int pos = r - cb * pitch;
-            const int f = lo + pos;
-            const bool valid = f >= 0 && f < p.in_valid;
-            const float* src = xf + ((bl * 16 + cb * 8) * pitch + pos);
+#pragma unroll
+        for (int q = 0; q < kNF; ++q) {
+            if (fsrc[q] == -2) continue;
             unsigned h[3][8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float v = valid ? src[k * pitch] : 0.f;
+                float v = fsrc[q] >= 0 ? xf[fsrc[q] + k * pitch] : 0.f;
                 if (LEAKY) v = v > 0.f ? v : v * p.in_slope;
                 split3(v, h[0][k], h[1][k], h[2][k]);
             }
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(const ConvP p) {
                 u32x4 pk;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
-                *reinterpret_cast<u32x4*>(xb + (size_t)(((bl * 2 + cb) * 3 + s3) * pitch + pos) * 16) = pk;
+                *reinterpret_cast<u32x4*>(xb + (size_t)(fdst[q] + s3 * pitch) * 16) = pk;
             }
         }
         __syncthreads();      // bf16 tile ready; the f32 stage is free again
@@ -227,7 +238,7 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     p.pitch = (width + 3 + 3) & ~3;
     const int x_slots = p.nb * 16 * (p.pitch >> 2);
     const int w16 = p.ph_ntaps[0] * 2 * 3 * kBM;
-    if (rh_cdiv(x_slots, 256) > kNXS || rh_cdiv(w16, 256) > kNWS) return false;
+    if (rh_cdiv(x_slots, 256) > kNXS || rh_cdiv(w16, 256) > kNWS || p.nb * 2 * p.pitch > 3 * 256) return false;
     p.x6_xf_floats = (p.nb * 16 * p.pitch + 255) & ~255;
     p.x6_xb_bytes = p.nb * 2 * 3 * p.pitch * 16;
     p.x6_w_bytes = ((w16 + 63) & ~63) * 16;
