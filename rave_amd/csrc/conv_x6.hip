@@ -224,6 +224,9 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     if (p.in_act == RH_ACT_SNAKE || p.epi_act == RH_ACT_SNAKE) return false;
     if (!rh_x6_weights(p.M, p.C, p.ph_ntaps[0], p.nphase, p.is, p.os, p.inner) || p.x6_packed == 0) return false;
     if ((p.in_row & 3) || ((uintptr_t)p.in & 15) || ((uintptr_t)p.wp & 15)) return false;
+    // pointwise convs on few channels: 18 MFMAs per 16-channel chunk do not amortise the conversion pass and its two
+    // barriers (measured at C = 96: 67 us vs 54 us for the f32 kernel on the data gradient)
+    if (p.ph_ntaps[0] == 1 && p.C < 192) return false;
     int bnl = kBN;
     if (p.ncols < kBN) {
         bnl = 32;
