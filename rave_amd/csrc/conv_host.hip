@@ -140,10 +140,40 @@ void plan_to_params(const TapPlan& t, ConvP* p) {
     for (int i = 0; i < t.nslots; ++i) p->off[i] = t.off[i];
 }
 
-// One 32 (m) x 32 (c) tile of one slot of one packed copy per workgroup, through LDS: the source is read along its
-// contiguous index ((m*C + c)*k + kk is contiguous-ish in c for the m-major copies, in m for the others), the packed
-// f32 tensor is written along m, and -- for layers the bf16x6 kernels can take (conv_x6.hip) -- the same tile is
-// split exactly into three bf16 pieces and written as 16-byte fragments of 8 channels ([slot][C/8][3][Mp][8]).
+// bf16x6 section of a packed operand (conv_x6.hip): layout mode and size in 16-byte fragments
+int x6_mode_of(const TapPlan& t, int inner) {
+    return rh_x6_mode(t.C, t.nphase, t.is, inner, t.ntaps[0], t.off, t.kk);
+}
+long x6_units(const TapPlan& t, int mode, long* ph_ofs = nullptr) {
+    const long Mp = round32(t.M);
+    if (mode == 0) return 0;
+    if (mode == 1) {
+        long u = 0;
+        for (int ph = 0; ph < t.nphase; ++ph) {
+            if (ph_ofs) ph_ofs[ph] = u;
+            u += (long)(t.C >> 4) * t.ntaps[ph] * 6 * Mp;
+        }
+        return u;
+    }
+    if (ph_ofs) ph_ofs[0] = 0;
+    return (long)((t.C * mode) >> 4) * rh_cdiv(t.ntaps[0], mode) * 6 * Mp;
+}
+void plan_to_x6(const TapPlan& t, int inner, ConvP* p) {
+    p->x6_mode = x6_mode_of(t, inner);
+    long units = x6_units(t, p->x6_mode, p->ph_q2ofs);
+    if (units * 4 >= 0x7fffffffl) { p->x6_mode = 0; units = 0; }      // same bound as the packers
+    p->x6_nu = p->x6_mode > 1 ? rh_cdiv(t.ntaps[0], p->x6_mode) : 0;
+    p->x6_wofs = (long)t.nslots * t.C * round32(t.M);
+    p->wq_bytes = units * 16 < 0xffffffffl ? (unsigned)(units * 16) : 0xffffffffu;
+}
+
+// One 32 (c) x 32 (m) tile of ALL slots of one packed copy per workgroup, through LDS (8 slots per pass): the source is
+// read along its contiguous index ((m*C + c)*k + kk for the m-major copies, (c*M + m)*k + kk for the others), the
+// packed f32 tensor is written along m, and -- for geometries the bf16x6 kernels take (conv_x6.hip) -- the same values
+// are split exactly into three bf16 pieces and written as 16-byte fragments of 8 K values in the order that kernel
+// walks them ([phase][step][g][piece][Mp], layouts in conv_params.hpp).
+constexpr int kPackSlots = 8;
+
 __device__ __forceinline__ void split3_bits(float x, unsigned& a, unsigned& b, unsigned& c) {
     a = __float_as_uint(x) & 0xffff0000u;
     const float r1 = x - __uint_as_float(a);
@@ -153,57 +183,90 @@ __device__ __forceinline__ void split3_bits(float x, unsigned& a, unsigned& b, u
 }
 
 __host__ __device__ __forceinline__ long pack_tiles(const PackP& q) {
-    return q.total ? (q.total / ((long)q.C * q.Mp)) * (q.Mp / 32) * ((q.C + 31) / 32) : 0;
+    return q.total ? (long)(q.Mp / 32) * ((q.C + 31) / 32) : 0;
 }
 
-__device__ __forceinline__ void pack_tile(const PackP& q, long tile, float (*lds)[33]) {
-    const int ct = (q.C + 31) / 32, mt = q.Mp / 32;
+__device__ __forceinline__ void emit_fragment(const float (&v)[8], unsigned* dst, long piece_stride_u32) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned h[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split3_bits(v[i], h[0][i], h[1][i], h[2][i]);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        u32x4 pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
+        *reinterpret_cast<u32x4*>(dst + s3 * piece_stride_u32) = pk;
+    }
+}
+
+__device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds /* [kPackSlots][32][33] */) {
+    const int ct = (q.C + 31) / 32;
     const int c0 = (int)(tile % ct) * 32;
-    tile /= ct;
-    const int m0 = (int)(tile % mt) * 32;
-    const int slot = (int)(tile / mt);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
-    const int kk = q.kk[slot];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                               // lds[c][m]
-        int m, c;
-        if (q.m_major) { m = m0 + ty + 8 * i; c = c0 + tx; }
-        else { c = c0 + ty + 8 * i; m = m0 + tx; }
-        float v = 0.f;
-        if (m < q.M && c < q.C) {
-            v = q.m_major ? q.w[((long)m * q.C + c) * q.k + kk] : q.w[((long)c * q.M + m) * q.k + kk];
-            if (q.scale) v *= q.scale[q.m_major ? m : c];       // dim 0 of the PyTorch weight tensor
+    const int m0 = (int)(tile / ct) * 32;
+    const int tid = threadIdx.x;
+    for (int s0 = 0; s0 < q.nslots; s0 += kPackSlots) {
+        const int ns = min(kPackSlots, q.nslots - s0);
+        for (int e = tid; e < ns * 1024; e += 256) {
+            const int sl = e % ns;
+            const int r = e / ns;
+            int cl, ml;
+            if (q.m_major) { cl = r & 31; ml = r >> 5; }
+            else { ml = r & 31; cl = r >> 5; }
+            const int m = m0 + ml, c = c0 + cl;
+            float v = 0.f;
+            if (m < q.M && c < q.C) {
+                const int kk = q.kk[s0 + sl];
+                v = q.m_major ? q.w[((long)m * q.C + c) * q.k + kk] : q.w[((long)c * q.M + m) * q.k + kk];
+                if (q.scale) v *= q.scale[q.m_major ? m : c];       // dim 0 of the PyTorch weight tensor
+            }
+            lds[(sl * 32 + cl) * 33 + ml] = v;
         }
-        lds[c - c0][m - m0] = v;
-    }
-    __syncthreads();
+        __syncthreads();
+        for (int e = tid; e < ns * 1024; e += 256) {
+            const int ml = e & 31, cl = (e >> 5) & 31, sl = e >> 10;
+            const int c = c0 + cl;
+            if (c < q.C) q.wp[((long)(s0 + sl) * q.C + c) * q.Mp + m0 + ml] = lds[(sl * 32 + cl) * 33 + ml];
+        }
+        if (q.wq && q.x6_mode == 1) {
+            for (int e = tid; e < ns * 128; e += 256) {
+                const int ml = e & 31, oct = (e >> 5) & 3, sl = e >> 7;
+                const int cb = c0 + oct * 8;
+                if (cb >= q.C) continue;
+                float v[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i, m = m0 + tx;
-        if (c < q.C) q.wp[((long)slot * q.C + c) * q.Mp + m] = lds[ty + 8 * i][tx];
-    }
-    if (q.wq && threadIdx.x < 128) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const int cb = threadIdx.x >> 5, m = threadIdx.x & 31;
-        if (c0 + cb * 8 < q.C) {
-            unsigned h[3][8];
+                for (int i = 0; i < 8; ++i) v[i] = lds[(sl * 32 + oct * 8 + i) * 33 + ml];
+                const int slot = s0 + sl;
+                const long unit = (long)q.q2a[slot] + (long)(cb >> 4) * q.q2n[slot] + (long)(((cb >> 3) & 1) * 3) * q.Mp + m0 + ml;
+                emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4);
+            }
+        } else if (q.wq && q.x6_mode > 1) {
+            const int IS = q.x6_mode, cpc = 16 / IS, nvc = 32 / cpc;
+            const int nug = (ns + IS - 1) / IS;                    // s0 is a multiple of IS (kPackSlots % IS == 0)
+            for (int e = tid; e < nug * nvc * 64; e += 256) {
+                const int ml = e & 31, g = (e >> 5) & 1;
+                const int r = e >> 6;
+                const int cv = r % nvc, ul = r / nvc;
+                const int cbase = c0 + cv * cpc;
+                if (cbase >= q.C) continue;
+                float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) split3_bits(lds[cb * 8 + k][m], h[0][k], h[1][k], h[2][k]);
-            u32x4* dst = reinterpret_cast<u32x4*>(q.wq) + (((long)slot * (q.C >> 3) + (c0 >> 3) + cb) * 3) * q.Mp + m0 + m;
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                u32x4 pk;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
-                dst[(long)s3 * q.Mp] = pk;
+                for (int i = 0; i < 8; ++i) {
+                    const int kap = 8 * g + i;
+                    const int cl = cv * cpc + kap / IS, sl = ul * IS + kap % IS;
+                    v[i] = sl < ns ? lds[(sl * 32 + cl) * 33 + ml] : 0.f;
+                }
+                const long unit = ((long)(cbase / cpc) * q.x6_nu + (s0 / IS + ul)) * 6 * q.Mp + (long)(g * 3) * q.Mp + m0 + ml;
+                emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4);
             }
         }
+        __syncthreads();
     }
 }
 
 // Both packed copies in one launch (forward operand, then data-gradient operand).
 __global__ __launch_bounds__(256) void pack_kernel(const PackP a, const PackP b) {
-    __shared__ float lds[32][33];
+    __shared__ float lds[kPackSlots * 32 * 33];
     const long t = blockIdx.x;
     const long na = pack_tiles(a);
     if (t < na) pack_tile(a, t, lds);
@@ -221,9 +284,24 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
     //   which=1: M = c_in.  Conv1d -> c-major (dim0 = c);  ConvT -> m_major (dim0 = m)
     p->m_major = t.src_m_major ? 1 : 0;
     p->total = (long)t.nslots * t.C * p->Mp;
+    p->nslots = t.nslots;
     for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
-    if (rh_x6_weights(t.M, t.C, t.nslots, t.nphase, t.is, t.os, d->inner) && !d->transposed)
-        p->wq = reinterpret_cast<unsigned short*>(wp + p->total);      // 16-byte aligned: Mp % 32 == 0
+    const int mode = x6_mode_of(t, d->inner);
+    long ph_ofs[kMaxPhases];
+    const long units = x6_units(t, mode, ph_ofs);
+    if (mode && units * 4 < 0x7fffffffl) {
+        p->wq = reinterpret_cast<unsigned*>(wp + p->total);            // 16-byte aligned: Mp % 32 == 0
+        p->x6_mode = mode;
+        if (mode == 1) {
+            for (int ph = 0; ph < t.nphase; ++ph)
+                for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
+                    p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 6 * p->Mp);
+                    p->q2n[t.tap0[ph] + tl] = t.ntaps[ph] * 6 * p->Mp;
+                }
+        } else {
+            p->x6_nu = rh_cdiv(t.ntaps[0], mode);
+        }
+    }
     return RH_OK;
 }
 
@@ -266,7 +344,7 @@ int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p) {
     p->epi_slope = 0.f;
     p->out_act = d->out_act;
     p->out_slope = d->out_slope;
-    p->x6_packed = !d->transposed;
+    plan_to_x6(t, d->inner, p);
     return RH_OK;
 }
 
@@ -289,7 +367,7 @@ int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p) {
     p->epi_slope = d->act_slope;
     p->out_act = RH_ACT_NONE;      // the caller pre-multiplies dy by out_act'(y) (rh_act_bwd_f32)
     p->out_slope = 0.f;
-    p->x6_packed = !d->transposed;
+    plan_to_x6(t, d->inner, p);
     return RH_OK;
 }
 
@@ -300,9 +378,9 @@ extern "C" int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which) {
     const int64_t n32 = (int64_t)d->kernel * C * round32((int)M);
     TapPlan t;
     if (build_plan(d, which, &t)) return -1;
-    // + the bf16x6 section (3 x 2 bytes per weight) for the layers conv_x6.hip can take
-    if (rh_x6_weights(t.M, t.C, t.nslots, t.nphase, t.is, t.os, d->inner) && !d->transposed) return n32 + n32 + n32 / 2;
-    return n32;
+    // + the bf16x6 section (3 x 2 bytes per K value, K padded to whole steps) for the geometries conv_x6.hip takes
+    const long units = x6_units(t, x6_mode_of(t, d->inner));
+    return units * 4 < 0x7fffffffl ? n32 + units * 4 : n32;
 }
 
 extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd,
@@ -360,7 +438,7 @@ __global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __rest
 }
 
 __global__ __launch_bounds__(256) void prep_pack_kernel(const PrepItem* __restrict__ items, int n) {
-    __shared__ float lds[32][33];
+    __shared__ float lds[kPackSlots * 32 * 33];
     const int it = find_item(items, n, blockIdx.x, false);
     const PrepItem& p = items[it];
     const long t = (long)blockIdx.x - p.blk_begin;
@@ -395,8 +473,7 @@ extern "C" int rh_prep_link(void* items, int32_t n, int64_t* total_rows, int64_t
         p[i].row_begin = rows;
         p[i].blk_begin = blks;
         rows += p[i].rows;
-        for (const PackP* q : {&p[i].fwd, &p[i].bwd})
-            if (q->total) blks += (q->total / ((long)q->C * q->Mp)) * (q->Mp / 32) * ((q->C + 31) / 32);
+        for (const PackP* q : {&p[i].fwd, &p[i].bwd}) blks += pack_tiles(*q);
     }
     *total_rows = rows;
     *total_blocks = blks;
@@ -451,6 +528,7 @@ extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const 
     RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv1d_fwd: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
     p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
+    p.wq = reinterpret_cast<const unsigned*>(wp_fwd + p.x6_wofs);
     p.in_alpha = snake_alpha; p.mul_alpha = nullptr;
     return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_fwd" : "conv1d_fwd", workspace,
                           workspace_bytes);
@@ -467,6 +545,7 @@ extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, 
     RH_REQUIRE(d->act == RH_ACT_NONE || x, RH_ERR_INVALID, "conv1d_bwd_data: act needs the forward input");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_data: snake needs alpha");
     p.in = dy; p.wp = wp_bwd; p.out = dx; p.bias = nullptr; p.add = add;
+    p.wq = reinterpret_cast<const unsigned*>(wp_bwd + p.x6_wofs);
     p.mul_src = d->act == RH_ACT_NONE ? nullptr : x;
     p.in_alpha = nullptr; p.mul_alpha = snake_alpha;
     return rh_conv_launch(p, (hipStream_t)stream, d->transposed ? "conv_transpose1d_bwd_data" : "conv1d_bwd_data",

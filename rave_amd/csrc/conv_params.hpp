@@ -39,10 +39,15 @@ struct ConvP {
     long part_stride;                          // B*M*out_row
     unsigned in_bytes, w_bytes;                // buffer sizes for the bounds-checked DMA descriptors
     // --- bf16x6 path (conv_x6.hip) only ---
-    const unsigned short* wq;                  // pre-split weights [slot][C/8][3][Mp][8] bf16 (caller scratch)
+    const unsigned* wq;                        // pre-split weights: 16-byte fragments [phase][step][g][piece][Mp] (8 bf16 each)
     unsigned wq_bytes;
-    int x6_xf_floats, x6_xb_bytes, x6_w_bytes; // LDS regions: f32 input stage, bf16 tile, one weight stage
-    int x6_packed;                             // the packed operand carries the bf16x6 section (rh_conv1d_* packers)
+    int x6_mode;                               // 0 = the packed operand has no bf16x6 section; else the input stride IS the
+                                               // section was packed for (1 = plain taps, 2 / 4 = phase-interleaved octets)
+    int x6_P;                                  // positions (16-byte fragments) per (octet, piece) plane of the B tile in LDS
+    int x6_a_units, x6_b_units;                // 16-byte units of one A stage / one B stage in LDS
+    int x6_nu;                                 // steps (taps or tap groups) per K chunk
+    long ph_q2ofs[kMaxPhases];                 // first fragment (16-byte units) of each phase in wq
+    long x6_wofs;                              // floats between wp and the bf16x6 section of the packed operand
     int nphase;
     int ph_oph[kMaxPhases], ph_ntaps[kMaxPhases], ph_tap0[kMaxPhases], ph_minoff[kMaxPhases],
         ph_maxoff[kMaxPhases];
@@ -85,11 +90,18 @@ struct PackP {
     const float* w;
     const float* scale;   // per dim-0 slice (weight-norm g/||v||) or null
     float* wp;
-    unsigned short* wq;   // bf16x6 section [slot][C/8][3][Mp][8] behind the f32 section (conv_x6.hip) or null
+    unsigned* wq;         // bf16x6 section behind the f32 section (conv_x6.hip) or null: 16-byte fragments of 8 bf16,
+                          //   [phase][step][g = octet of the 16-deep MFMA k block][piece 0..2][Mp]
     long total;           // nslots * C * Mp   (0 = nothing to do)
     int C, M, Mp, k;      // k = taps per (m, c) pair in the source tensor
+    int nslots;
     int m_major;          // source index = (m*C + c)*k + kk, else (c*M + m)*k + kk
+    int x6_mode;          // 0 none; 1: step = (16-channel chunk, tap); IS > 1: step = (16/IS-channel chunk, tap group u),
+                          //   k slot kappa of the block <-> channel kappa / IS, source tap u*IS + kappa % IS
+    int x6_nu;            // IS > 1: tap groups per chunk = ceil(k / IS)
     int kk[kMaxTaps];
+    int q2a[kMaxTaps];    // mode 1: fragment offset of (phase of the slot, chunk 0, tap-in-phase of the slot)
+    int q2n[kMaxTaps];    // mode 1: fragments per chunk in the phase of the slot (ntaps * 6 * Mp)
 };
 int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what);
 // dbias[m] = sum_{b,e} dy[b][m][e] * act'(y[b][m][e]) (y may be null): grid (M, 64) partials in `part`
@@ -107,8 +119,14 @@ int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws,
 bool rh_conv_dma_eligible(const ConvP& p);
 int64_t rh_conv_splitk_workspace(ConvP p);     // bytes of scratch the launch would like (0 = none)
 int64_t rh_conv_x6_workspace(ConvP p);         // bf16x6 path: scratch it needs, -1 = geometry not eligible
-// weights eligible for the bf16x6 kernels (decided from the geometry alone, so that packers and launchers agree)
-inline bool rh_x6_weights(int M, int C, int ntaps, int nphase, int is, int os, int inner) {
-    return nphase == 1 && is == 1 && os == 1 && inner == 1 && ntaps >= 1 && ntaps <= 3 && (C & 15) == 0 && M % 96 == 0;
+// Which bf16x6 operand layout a geometry gets (decided from the tap plan alone, so that packers and launchers agree):
+// 0 = none, 1 = plain taps (input stride 1, any number of output phases), 2 / 4 = phase-interleaved octets of a
+// strided gather (one phase, contiguous taps, dilation 1).
+inline int rh_x6_mode(int C, int nphase, int is, int inner, int ntaps0, const int* off, const int* kk) {
+    if (is == 1) return (C & 15) == 0 ? 1 : 0;
+    if (nphase != 1 || inner != 1 || (is != 2 && is != 4) || (C * is) % 16 != 0) return 0;
+    for (int t = 0; t < ntaps0; ++t)
+        if (off[t] != off[0] + t || kk[t] != t) return 0;
+    return is;
 }
 int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool* used);

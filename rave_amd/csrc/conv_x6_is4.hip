@@ -1,0 +1,8 @@
+// bf16x6 convolution kernels for input stride 4 (see conv_x6_kernel.inc).
+#include <mutex>
+#include "conv_params.hpp"
+#include "conv_x6_kernel.inc"
+
+void rh_x6_dispatch_is4(const ConvP& q, int tm, int wm, dim3 grid, size_t lds, hipStream_t stream) {
+    x6_dispatch<4>(q, tm, wm, grid, lds, stream);
+}

@@ -30,13 +30,17 @@ def test_descriptor_queries_and_errors():
     from rave_amd import _lib as L
     d = L.ConvDesc(batch=32, c_in=96, c_out=96, l_in=4096, l_out=4096, kernel=3, stride=1, dilation=9,
                    pad_left=9, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
-    # stride-1, C % 16 == 0, M % 96 == 0, <= 3 taps: f32 operand + the bf16x6 section (3 x 2 bytes per weight)
+    # K in blocks of 16: f32 operand + the bf16x6 section (3 x 2 bytes per weight)
     assert L.lib.rh_conv1d_packed_floats(C.byref(d), 0) == 3 * 96 * 96 * 5 // 2
     assert L.lib.rh_conv1d_packed_floats(C.byref(d), 1) == 3 * 96 * 96 * 5 // 2
     d0 = L.ConvDesc(batch=32, c_in=96, c_out=192, l_in=4096, l_out=1024, kernel=8, stride=4, dilation=1,
                     pad_left=3, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 0) == 8 * 96 * 192     # strided: f32 operand only
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 1) == 8 * 192 * 96
+    # strided: phase-interleaved octets (forward), per-phase taps (data gradient) -- same size
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 0) == 8 * 96 * 192 * 5 // 2
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 1) == 8 * 192 * 96 * 5 // 2
+    d1 = L.ConvDesc(batch=2, c_in=1, c_out=96, l_in=4096, l_out=1024, kernel=15, stride=4, dilation=1,
+                    pad_left=7, transposed=0, groups=1, inner=1, in_valid=0, act=0, act_slope=0.0)
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d1), 0) == 15 * 1 * 96       # C*stride % 16 != 0: f32 operand only
     assert L.lib.rh_conv1d_workspace_bytes(C.byref(d)) > 0
     assert L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)) == 0            # large grid: no split-K
     d2 = L.ConvDesc(batch=32, c_in=1536, c_out=256, l_in=32, l_out=32, kernel=3, stride=1, dilation=1,
