@@ -1123,6 +1123,7 @@ int fill_pack2(const rh_conv2d_desc* d, int which, const float* w, float* wp, Pa
     p->k = d->kh * d->kw;
     p->m_major = which == 0 ? 1 : 0;      // w[co][ci][kk]: forward m = co (m-major), data gradient m = ci (c-major)
     p->total = (long)t.nslots * p->C * p->Mp;
+    p->nslots = t.nslots;
     for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
     return RH_OK;
 }

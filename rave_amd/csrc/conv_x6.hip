@@ -23,6 +23,11 @@ bool x6_enabled() {
 bool plan_x6(ConvP& p, X6Plan* pl) {
     if (!x6_enabled() || p.x6_mode == 0 || p.x6_mode != p.is) return false;
     if (p.in_act == RH_ACT_SNAKE || p.epi_act == RH_ACT_SNAKE) return false;
+    {   // epilogue operand combinations the kernel carries a specialised copy for (bit 0 bias, 1 derivative, 2 add,
+        // 3 output activation); everything the modules use -- anything else takes the f32 kernels
+        const int mode = (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
+        if (!(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 9 || mode == 13)) return false;
+    }
     if (p.is != 1 && (p.inner != 1 || p.nphase != 1)) return false;
     if (((uintptr_t)p.wq & 15) || ((uintptr_t)p.in & 3)) return false;
     const int is = p.is;
@@ -95,6 +100,10 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
         pl.chunks_per_split = (q.C * q.is) >> 4;
     }
     q.in_bytes = (unsigned)(4ull * q.B * q.C * (unsigned long long)q.in_row);
+    {
+        const char* e = getenv("RH_X6_ABL");
+        q.x6_abl = e ? atoi(e) : 0;
+    }
     q.part = (float*)ws;
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;

@@ -1,5 +1,6 @@
 // bf16x6 convolution kernels for input stride 1 (see conv_x6_kernel.inc).
 #include <mutex>
+#include <type_traits>
 #include "conv_params.hpp"
 #include "conv_x6_kernel.inc"
 

@@ -32,6 +32,16 @@ def _pqmf_encode(pq, x: torch.Tensor):
     return x_multiband.reshape(*batch_size, -1, x_multiband.shape[-1])
 
 
+def valid_signal_crop(x: torch.Tensor, left_rf, right_rf):
+    """rave/core.py:220-225: drop the samples the receptive field does not fully cover (in band samples: the
+    receptive field is measured in audio samples, ``dim`` = the multiband channel count)."""
+    dim = x.shape[1]
+    x = x[..., int(left_rf) // dim:]
+    if int(right_rf):
+        x = x[..., :-int(right_rf) // dim]
+    return x
+
+
 def _pqmf_decode(pq, x: torch.Tensor, batch_size, n_channels: int):
     """rave/model.py:125-130."""
     x = x.reshape(x.shape[0] * n_channels, -1, x.shape[-1])
@@ -69,6 +79,7 @@ class RAVE(nn.Module):
         self.register_buffer("receptive_field", torch.tensor([0, 0]).long())
         self.logged: Dict[str, torch.Tensor] = {}
         self._opts = None
+        self._gen_sched = None
         self._prep = None
         # OPT-IN (default off = the reference's exact work per step): skip gradient work
         # whose result the reference computes and then discards -- on generator steps the discriminator's weight
@@ -101,7 +112,18 @@ class RAVE(nn.Module):
         gen_opt = torch.optim.Adam(gen_p, 1e-3, (.5, .9), fused=fused)
         dis_opt = torch.optim.Adam(dis_p, 1e-4, (.5, .9), fused=fused)
         self._opts = (gen_opt, dis_opt)
+        # rave/model.py:234-236: the generator learning rate decays linearly to 0.1x over phase 1
+        self._gen_sched = torch.optim.lr_scheduler.LinearLR(gen_opt, start_factor=1.0, end_factor=0.1,
+                                                            total_iters=self.warmup)
         return gen_opt, dis_opt
+
+    def lr_schedulers(self):
+        self.optimizers()
+        return self._gen_sched
+
+    def on_train_batch_end(self, outputs=None, batch=None, batch_idx=None) -> None:
+        """rave/model.py:272-274 (Lightning hook; a driver loop calls it after every training_step)."""
+        self.lr_schedulers().step()
 
     def optimizers(self):
         if self._opts is None:
@@ -160,8 +182,9 @@ class RAVE(nn.Module):
         y_raw = y_raw[..., :x_raw.shape[-1]]
         y_multiband = y_multiband[..., :x_multiband.shape[-1]]
 
-        if self.valid_signal_crop and self.receptive_field.sum():
-            raise NotImplementedError("valid_signal_crop with a measured receptive field")
+        if self.valid_signal_crop and self.receptive_field.sum():     # rave/model.py:321-329
+            x_multiband = valid_signal_crop(x_multiband, *self.receptive_field)
+            y_multiband = valid_signal_crop(y_multiband, *self.receptive_field)
 
         distances = {}
         multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
@@ -181,11 +204,13 @@ class RAVE(nn.Module):
                 xy = torch.cat([x_raw, y_raw], 0)
             if self.skip_dead_grads and not dis_step:
                 frozen = [q for q in self.discriminator.parameters() if q.requires_grad]
+            try:
                 for q in frozen:
                     q.requires_grad_(False)
-            features = self.discriminator(xy)
-            for q in frozen:
-                q.requires_grad_(True)
+                features = self.discriminator(xy)
+            finally:
+                for q in frozen:
+                    q.requires_grad_(True)
             feature_real, feature_fake = self.split_features(features)
             loss_dis = 0
             loss_adv = 0

@@ -213,3 +213,39 @@ def test_reference_blocks_build_on_the_drop_in_operator_package():
     assert hip["conv_modules"] == ["rave_amd.cc"]
     # buffers the real package may add for streaming ("...pad") are not part of either build
     assert hip["shapes"] == ref["shapes"]
+
+
+def test_valid_signal_crop_and_lr_schedule_match_reference():
+    """rave/core.py:220-225 and rave/model.py:234-236,272-274 restated in rave_amd/model.py."""
+    import torch
+    from rave_amd import model as M
+    x = torch.arange(2 * 16 * 100, dtype=torch.float32).reshape(2, 16, 100)
+    lf, rf = torch.tensor(1234), torch.tensor(567)
+    got = M.valid_signal_crop(x, lf, rf)
+    assert torch.equal(got, x[..., 1234 // 16:-567 // 16])
+    assert torch.equal(M.valid_signal_crop(x, torch.tensor(40), torch.tensor(0)), x[..., 2:])
+    from ref_import import reference_available, import_reference
+    if reference_available():
+        rave = import_reference()
+        assert torch.equal(got, rave.core.valid_signal_crop(x, lf, rf))
+    # generator LR: LinearLR 1.0 -> 0.1 over phase_1_duration steps, stepped once per batch
+    lin = torch.nn.Linear(2, 2)
+
+    class Tiny(M.RAVE):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.encoder, self.decoder, self.discriminator = lin, torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+            self.warmup = 10
+            self._opts = self._gen_sched = None
+
+    m = Tiny()
+    gen_opt, dis_opt = m.optimizers()
+    for _ in range(5):
+        gen_opt.step()
+        m.on_train_batch_end(None, None, 0)
+    assert abs(gen_opt.param_groups[0]["lr"] - 1e-3 * (1.0 - 0.9 * 5 / 10)) < 1e-12
+    assert dis_opt.param_groups[0]["lr"] == 1e-4
+    for _ in range(10):
+        gen_opt.step()
+        m.on_train_batch_end(None, None, 0)
+    assert abs(gen_opt.param_groups[0]["lr"] - 1e-4) < 1e-12

@@ -80,3 +80,59 @@ def test_grad_reducer_overlapped(tmp_path):
 
 def test_grad_reducer_flush_only(tmp_path):
     _run(False, tmp_path)
+
+
+class _EmaNet(nn.Module):
+    """A buffer updated from LOCAL batch statistics (the RVQ codebooks / BatchNorm running stats pattern)."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(4, 4)
+        self.register_buffer("ema", torch.zeros(4))
+        self.register_buffer("count", torch.zeros((), dtype=torch.long))
+
+    def forward(self, x):
+        if self.training:
+            with torch.no_grad():
+                self.ema.mul_(0.9).add_(x.mean(0), alpha=0.1)
+                self.count += 1
+        return self.lin(x - self.ema)
+
+
+def _buf_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rave_amd.ddp import BufferSync
+    torch.manual_seed(0)
+    net = _EmaNet()
+    sync = BufferSync(net)
+    torch.manual_seed(10 + rank)                 # every rank sees different data
+    for step in range(3):
+        sync.sync()                              # start of step: rank-0 buffers everywhere
+        net(torch.randn(16, 4) + rank)
+    sync.sync()
+    torch.save((net.ema.clone(), net.count.clone(), sync.bytes_sent), os.path.join(outdir, f"buf{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_buffer_sync_keeps_ranks_on_rank0_statistics(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_buf_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    e0, c0, sent = torch.load(os.path.join(str(tmp_path), "buf0.pt"), weights_only=False)
+    e1, c1, _ = torch.load(os.path.join(str(tmp_path), "buf1.pt"), weights_only=False)
+    assert torch.equal(e0, e1) and torch.equal(c0, c1) and int(c0) == 3 and sent == 4 * 4 * 4
+    # rank 0 alone (torch DDP semantics: its buffers win)
+    torch.manual_seed(0)
+    ref = _EmaNet()
+    torch.manual_seed(10)
+    for step in range(3):
+        ref(torch.randn(16, 4))
+    assert torch.equal(ref.ema, e0)
