@@ -259,9 +259,9 @@ def golden_v1_tiny(name="v1_tiny.pt"):
     print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients", tuple(noise.shape))
 
 
-def _subsample(g, step=257):
+def _subsample(g, step=257, keep=200_000):
     g = g.reshape(-1)
-    return t(g) if g.numel() <= 200_000 else t(g[::step])
+    return t(g) if g.numel() <= keep else t(g[::step])
 
 
 def golden_disc2d(name="disc2d_tiny.pt"):
@@ -437,6 +437,67 @@ def golden_discrete_step_tiny(name="discrete_step_tiny.pt"):
     print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
 
 
+
+def golden_v2_wide(name="v2_wide.pt"):
+    """BASELINE configs[1] at its REAL width (v2.gin: CAPACITY 96, latent 128 -- 31.5 M generator-side weights,
+    every conv at the channel count the benchmark runs), short clips (2 x 8192 samples): the reference's own
+    encode -> reparametrize -> decode and its autograd backward under seeded cotangents at y_raw / y_mb (+ the KL
+    term).  The weights come from rave_oracle.seeded_state_dict (the fixture carries the SEED); stored are the
+    outputs, every weight_g gradient in full and every weight_v gradient subsampled (every 257th element).
+    This is the fixture that reaches the bf16x6 kernels and the C = 768 / 1536 weight gradients with
+    reference-produced numbers (the CAPACITY-6 fixtures never do)."""
+    seed, batch, n_signal = 303, 2, 8192
+    torch.manual_seed(0)
+    m = build_reference_rave("v2", capacity=96, latent_size=128)
+    m.train()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith(("encoder.", "decoder."))}
+    sd = O.seeded_state_dict(shapes, seed)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not any(k in sd for k in res.missing_keys)
+    assert all(k in sd for k, _ in m.named_parameters() if k.startswith(("encoder.", "decoder.")))
+    x = O.synthetic_batch(batch, 1, n_signal, seed=5)
+    g = torch.Generator().manual_seed(17)
+    zp, x_mb = m.encode(x, return_mb=True)
+    torch.manual_seed(1234)
+    z, reg = m.encoder.reparametrize(zp)[:2]
+    torch.manual_seed(1234)
+    eps = torch.randn(z.shape)
+    y_mb = m.decoder(z)
+    y_raw = m.decode(z)[..., :n_signal]
+    cy_raw = torch.randn(y_raw.shape, generator=g) * 1e-3
+    cy_mb = torch.randn(y_mb.shape, generator=g) * 1e-3
+    m.zero_grad(set_to_none=True)
+    torch.autograd.backward([y_raw, y_mb, reg], [cy_raw, cy_mb, torch.ones(())])
+    grads = {}
+    for k, p in m.named_parameters():
+        if k.startswith(("encoder.", "decoder.")) and p.grad is not None:
+            grads[k] = t(p.grad) if k.endswith("weight_g") else _subsample(p.grad, keep=20_000)
+    # the same step by the same reference modules in float64: weight-norm gain gradients are sums with heavy
+    # cancellation, so two fp32 implementations differ by up to ~1e-3 on a few of them; the parity tests judge
+    # the HIP gradient against this value with the reference's own fp32 deviation as the yardstick
+    m.double()
+    m.zero_grad(set_to_none=True)
+    zp64, _ = m.encode(x.double(), return_mb=True)
+    mean, scale = zp64.chunk(2, 1)
+    std = torch.nn.functional.softplus(scale) + 1e-4
+    z64 = eps.double() * std + mean
+    reg64 = (mean * mean + std * std - 2 * std.log() - 1).sum(1).mean()
+    y_mb64 = m.decoder(z64)
+    y_raw64 = m.decode(z64)[..., :n_signal]
+    torch.autograd.backward([y_raw64, y_mb64, reg64], [cy_raw.double(), cy_mb.double(), torch.ones((), dtype=torch.float64)])
+    assert abs(float(reg64) - float(reg)) < 1e-4 * abs(float(reg))
+    grads64 = {}
+    for k, p in m.named_parameters():
+        if k.startswith(("encoder.", "decoder.")) and p.grad is not None:
+            grads64[k] = t(p.grad) if k.endswith("weight_g") else _subsample(p.grad, keep=20_000)
+    m.float()
+    out = dict(grads64=grads64, config=dict(capacity=96, latent_size=128, n_signal=n_signal, batch=batch), seed=seed, shapes=shapes,
+               x=t(x), eps=eps, x_mb=t(x_mb), z_params=t(zp), z=t(z), reg=t(reg), y_mb=t(y_mb), y_raw=t(y_raw),
+               cot_y_raw=cy_raw, cot_y_mb=cy_mb, grads=grads, grad_step=257, grad_keep=20_000)
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", len(grads), "gradients; reg", float(reg))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_pqmf()
@@ -449,3 +510,4 @@ if __name__ == "__main__":
     golden_rvq()
     golden_v3_step_tiny()
     golden_discrete_step_tiny()
+    golden_v2_wide()

@@ -995,3 +995,243 @@ def test_discrete_spectral_training_step_golden(golden_dir, dev, tag, idx):
             if err > 5e-4 * float(want.double().norm()) + 1e-5:
                 bad.append((k, err, float(want.double().norm())))
         assert not bad, bad[:5]
+
+
+# --------------------------------------------------------------------------- full width (CAPACITY 96)
+# The benchmarked geometry: every conv of the generator side at its real channel count (96 ... 1536), so that the
+# bf16x6 kernels (conv_x6_kernel.inc: every tile shape, split-K, batch folding at the short stages, the
+# phase-interleaved strided form, the per-phase transposed form) and the weight gradients at C = 768 / 1536 are
+# compared with the CPU oracle INSIDE the module graph, forward and backward.
+def _full_width_grads(dev, batch, x6_mode):
+    import os
+    from rave_amd import model as M
+    cfg = O.v2_config()
+    sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+    x = O.synthetic_batch(batch, 1, 65536)
+    gen = torch.Generator().manual_seed(7)
+    eps = torch.randn(batch, 128, 32, generator=gen)
+    # cotangents at the hot-path outputs, of the size class the loss produces there
+    cy_raw = torch.randn(batch, 1, 65536, generator=gen) * 1e-3
+    cy_mb = torch.randn(batch, 16, 4096, generator=gen) * 1e-3
+    # --- CPU oracle, fp32 (the reference's arithmetic) and fp64 (the yardstick for ill-conditioned gradients)
+    sdr = {k: (v.clone().requires_grad_(v.is_floating_point() and not k.startswith("pqmf."))) for k, v in sd.items()}
+    out = O.rave_forward(x, sdr, cfg, eps)
+    torch.autograd.backward([out["y_raw"], out["y_mb"], out["reg"]], [cy_raw, cy_mb, torch.ones(())])
+    sd64 = {k: (v.double().requires_grad_(not k.startswith("pqmf.")) if v.is_floating_point() else v) for k, v in sd.items()}
+    out64 = O.rave_forward(x.double(), sd64, cfg, eps.double())
+    torch.autograd.backward([out64["y_raw"], out64["y_mb"], out64["reg"]],
+                            [cy_raw.double(), cy_mb.double(), torch.ones((), dtype=torch.float64)])
+    for k, v in sdr.items():
+        v.grad64 = sd64[k].grad if torch.is_tensor(sd64[k]) and sd64[k].is_floating_point() else None
+    # --- HIP path
+    old = os.environ.get("RH_CONV_X6")
+    os.environ["RH_CONV_X6"] = x6_mode
+    try:
+        m = M.build_v2()
+        m.load_state_dict(sd, strict=False)
+        m = m.to(dev).train()
+        m.prepare_weights()
+        zp, x_mb = m.encode(x.to(dev), return_mb=True)
+        z, reg = m.encoder.reparametrize(zp, eps.to(dev))
+        y_mb = m.decoder(z)
+        y_raw = m.decode(z)
+        torch.autograd.backward([y_raw, y_mb, reg], [cy_raw.to(dev), cy_mb.to(dev), torch.ones((), device=dev)])
+        m.release_weights()
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("RH_CONV_X6", None)
+        else:
+            os.environ["RH_CONV_X6"] = old
+    return m, sdr, out, dict(x_mb=x_mb, z_params=zp, y_mb=y_mb, y_raw=y_raw)
+
+
+@pytest.mark.parametrize("x6_mode", ["1", "0"])
+def test_v2_full_width_hot_path_forward_backward_vs_oracle(dev, x6_mode):
+    """BASELINE configs[1] geometry (v2, CAPACITY 96, n_signal 65536), batch 2, forward AND backward of
+    PQMF -> EncoderV2 -> reparametrize -> GeneratorV2 -> PQMF^-1 with fixed cotangents at y_raw / y_mb: every
+    encoder / decoder parameter gradient vs the CPU oracle, <= 2e-4 relative L2 (north_star: 1e-4 on outputs),
+    on the bf16x6 kernels (RH_CONV_X6=1, the benchmarked path) and on the exact-f32 MFMA kernels (=0)."""
+    m, sdr, ref, got = _full_width_grads(dev, 2, x6_mode)
+    assert rel_l2(got["x_mb"], ref["x_mb"]) < TOL_OP
+    for k in ("z_params", "y_mb", "y_raw"):
+        assert rel_l2(got[k], ref[k]) < TOL_E2E, k
+    named = dict(m.named_parameters())
+    checked, worst = 0, 0.0
+    for k, v in sdr.items():
+        if not (k.startswith("encoder.") or k.startswith("decoder.")) or v.grad is None:
+            continue
+        assert named[k].grad is not None, k
+        # weight-norm gain gradients are sums with heavy cancellation: the fp32 oracle (= the reference's own
+        # arithmetic) is itself up to ~1e-3 away from the fp64 value on a few of them; the HIP gradient must be as
+        # close to the fp64 value as the reference's fp32 is (x3), and within 2e-4 wherever that is well-conditioned
+        ref_err = rel_l2(v.grad, v.grad64)
+        err = rel_l2(named[k].grad, v.grad64)
+        worst = max(worst, err)
+        # gains: d/dg = <dw, v>/||v|| is a projection with heavy cancellation (the wgrad error of 1e-6 of the term
+        # magnitudes shows up 100x larger in it) -> 1e-3; directions: 2e-4
+        tol = 1e-3 if k.endswith("weight_g") else 2e-4
+        assert err < max(tol, 3.0 * ref_err), (k, err, ref_err)
+        checked += 1
+    assert checked == 112, checked          # 56 weight-normalised convs x (g, v)
+    assert worst > 0.0
+
+
+def test_v2_full_width_x6_kernels_are_the_ones_that_ran(dev):
+    """The two modes of the test above must really be two code paths: with RH_CONV_X6=1 the v2 forward differs
+    from the exact-f32 kernels in the last bits (3-way bf16 split, 1.5x an fmaf chain) -- but by no more."""
+    import os
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    g = ConvGeom(stride=1, dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 192, 1024, generator=gen).to(dev)
+    w = (torch.randn(192, 192, 3, generator=gen) * 0.05).to(dev)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["RH_CONV_X6"] = mode
+        outs[mode] = R.conv1d(x, w, None, geom=g)
+    os.environ.pop("RH_CONV_X6", None)
+    d = rel_l2(outs["1"], outs["0"])
+    assert 0.0 < d < 2e-6, d
+
+
+def test_v2_full_width_reference_golden(golden_dir, dev):
+    """tests/golden/v2_wide.pt: the REFERENCE's own modules at CAPACITY 96 (seeded weights, 2 x 8192 samples):
+    outputs and all 112 generator-side parameter gradients under the stored cotangents, on the bf16x6 kernels."""
+    from rave_amd import model as M
+    g = _load(golden_dir, "v2_wide.pt")
+    m = M.build_v2(capacity=g["config"]["capacity"], latent_size=g["config"]["latent_size"])
+    sd = O.seeded_state_dict(g["shapes"], g["seed"])
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not any(k in sd for k in res.missing_keys)
+    m = m.to(dev).train()
+    x = g["x"].to(dev)
+    zp, x_mb = m.encode(x, return_mb=True)
+    z, reg = m.encoder.reparametrize(zp, g["eps"].to(dev))
+    y_mb = m.decoder(z)
+    y_raw = m.decode(z)[..., :x.shape[-1]]
+    assert rel_l2(x_mb, g["x_mb"]) < TOL_OP
+    for got, k in ((zp, "z_params"), (y_mb, "y_mb"), (y_raw, "y_raw")):
+        assert rel_l2(got, g[k]) < TOL_E2E, k
+    assert abs(float(reg) - float(g["reg"])) <= 1e-5 * abs(float(g["reg"]))
+    torch.autograd.backward([y_raw, y_mb, reg], [g["cot_y_raw"].to(dev), g["cot_y_mb"].to(dev), torch.ones((), device=dev)])
+    named = dict(m.named_parameters())
+    assert len(g["grads"]) == 112
+    for k, gref in g["grads"].items():
+        got = named[k].grad.reshape(-1)
+        got = got if got.numel() <= g["grad_keep"] else got[::g["grad_step"]]
+        g64 = g["grads64"][k]
+        ref_err = rel_l2(gref, g64)          # the reference's own fp32 deviation from its fp64 evaluation
+        err = rel_l2(got, g64)
+        assert err < max(2e-4, 3.0 * ref_err), (k, err, ref_err)
+        assert rel_l2(got, gref) < max(2e-4, 4.0 * ref_err), (k, rel_l2(got, gref), ref_err)
+
+
+def _hinge_step_vs_oracle(dev, model, feats_ref_fn, xy, tol=5e-4):
+    """One discriminator step (hinge loss on the last feature map of every net, rave/model.py:362-374) of a
+    full-width discriminator: every feature map and the loss value vs the fp32 CPU oracle; every parameter gradient
+    vs the fp64 oracle, with the fp32 oracle's own deviation as the yardstick.
+
+    The hinge gates (relu(1 -+ score)) make the gradient DISCONTINUOUS in the scores: a score within rounding of the
+    hinge flips its gate between two fp32 implementations and moves whole gradient tensors by ~1e-3 (measured: the
+    fp32 CPU oracle itself is 5e-4 ... 3e-3 away from its fp64 evaluation on this step).  So the gates are taken from
+    ONE place -- the fp32 oracle's dL/dscore is injected at the score maps of all three evaluations -- which leaves
+    the backward through the networks (linear in the cotangent) as the thing compared."""
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.endswith(".window")}
+    sd = O.seeded_state_dict(shapes, 11)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith(".window") for k in res.missing_keys)
+    model.to(dev).train()
+
+    def hinge(feats):
+        loss = 0.0
+        for net in feats:
+            real, fake = net[-1][: net[-1].shape[0] // 2], net[-1][net[-1].shape[0] // 2:]
+            loss = loss + torch.relu(1 - real).mean() + torch.relu(1 + fake).mean()
+        return loss
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_feats = feats_ref_fn(xy, leaves)
+    ref_loss = hinge(ref_feats)
+    scores = [net[-1] for net in ref_feats]
+    cots = torch.autograd.grad(ref_loss, scores, retain_graph=True)
+    torch.autograd.backward(scores, cots)
+    leaves64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    f64 = feats_ref_fn(xy.double(), leaves64)
+    torch.autograd.backward([net[-1] for net in f64], [c.double() for c in cots])
+    got_feats = model(xy.to(dev))
+    got_loss = hinge(got_feats)
+    torch.autograd.backward([net[-1] for net in got_feats], [c.to(dev) for c in cots])
+    assert [len(n) for n in got_feats] == [len(n) for n in ref_feats]
+    worst = 0.0
+    for net, rnet in zip(got_feats, ref_feats):
+        for f, rf in zip(net, rnet):
+            assert f.shape == rf.shape
+            worst = max(worst, rel_l2(f, rf))
+    assert worst < TOL_E2E, worst
+    assert abs(float(got_loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    bad, loose, checked = [], [], 0
+    for k, p in model.named_parameters():
+        want = leaves64[k].grad
+        if want is None:
+            continue
+        norm = float(want.norm())
+        ref_err = float((leaves[k].grad.double() - want).norm())
+        err = float((p.grad.detach().double().cpu() - want).norm())
+        # absolute floor: hinge puts -1/N on real and +1/N on fake scores, so the last conv's bias gradient cancels
+        # to rounding noise in the reference too
+        if err > max(tol * norm, 3.0 * ref_err) + 1e-6:
+            bad.append((k, err, ref_err, norm))
+        if err > max(3e-3 * norm, 3.0 * ref_err) + 1e-6:
+            loose.append((k, err, ref_err, norm))
+        checked += 1
+    # LeakyReLU gates INSIDE the networks are discontinuous too: a pre-activation within rounding of zero takes the
+    # other slope in another fp32 implementation, which changes that element's gradient 10x (slope 0.1) and -- with
+    # the sparse hinge cotangent -- moves everything upstream of it by ~0.9/sqrt(numel) ~ 7e-4 (measured: exactly
+    # one flipped element of 1.67 M in the last MPD layer of period 11; with dense random cotangents the same
+    # kernels agree with the exact-f32 kernels to 1e-6, tools/debug/descript_x6_vs_f32.py).  So: every gradient
+    # within 3e-3 (a handful of flips), and all but a few (one net's chain) within the tight bound.
+    assert not loose, loose[:5]
+    assert len(bad) <= max(6, checked // 8), bad[:8]
+    assert checked >= 10
+
+
+def test_full_width_v2_discriminator_step_vs_oracle(dev):
+    """BASELINE configs[2] discriminator (v2.gin:53-75: MPD + MSD, CAPACITY 96), 65536 samples, x and y of one clip."""
+    from functools import partial
+    import torch.nn as nn
+    from rave_amd import discriminator as D
+    cfg = O.v2_config()
+    common = dict(out_size=1, capacity=96, n_layers=4, stride=4)
+    mpd = partial(D.MultiPeriodDiscriminator, periods=[2, 3, 5, 7, 11],
+                  convnet=partial(D.ConvNet, conv=nn.Conv2d, kernel_size=(5, 1), **common))
+    msd = partial(D.MultiScaleDiscriminator, n_discriminators=3,
+                  convnet=partial(D.ConvNet, conv=nn.Conv1d, kernel_size=15, **common))
+    model = D.CombineDiscriminators(discriminators=[mpd, msd], n_channels=1)
+    xy = torch.cat([O.synthetic_batch(1, 1, 65536, seed=41), O.synthetic_batch(1, 1, 65536, seed=42) * 0.7], 0)
+    _hinge_step_vs_oracle(dev, model, lambda x, sd: O.combine_discriminators(
+        x, {"discriminator." + k: v for k, v in sd.items()}, cfg), xy)
+
+
+def test_full_width_spectral_discriminator_step_vs_oracle(dev):
+    """BASELINE configs[3] discriminator side at full width (spectral_discriminator.gin: Encodec STFT nets, capacity
+    32, scales 4096 ... 256), 65536 samples."""
+    from functools import partial
+    from rave_amd import discriminator as D
+    scales = [4096, 2048, 1024, 512, 256]
+    model = D.MultiScaleSpectralDiscriminator(scales, partial(D.EncodecConvNet, capacity=32), n_channels=1)
+    xy = torch.cat([O.synthetic_batch(1, 1, 65536, seed=43), O.synthetic_batch(1, 1, 65536, seed=44) * 0.7], 0)
+    _hinge_step_vs_oracle(dev, model, lambda x, sd: O.multiscale_spectral_discriminator(
+        x, {"d." + k: v for k, v in sd.items()}, "d", scales), xy)
+
+
+def test_full_width_descript_discriminator_step_vs_oracle(dev):
+    """BASELINE configs[4] discriminator (v3.gin: descript MPD 2,3,5,7,11 + MRD 2048/1024/512), stereo, 65536
+    samples, x and y of one clip: the 42.6 M-parameter network at its real size."""
+    from rave_amd import descript_discriminator as DD
+    periods, ffts = [2, 3, 5, 7, 11], [2048, 1024, 512]
+    model = DD.DescriptDiscriminator(periods=periods, fft_sizes=ffts, n_channels=2)
+    xy = torch.cat([O.synthetic_batch(1, 2, 65536, seed=45), O.synthetic_batch(1, 2, 65536, seed=46) * 0.7], 0)
+    _hinge_step_vs_oracle(dev, model, lambda x, sd: O.descript_discriminator(
+        x, {"d." + k: v for k, v in sd.items()}, "d", periods, ffts), xy)

@@ -367,3 +367,27 @@ def test_oracle_noncached_pqmf_variants_match_reference():
                              (False, O.pqmf_classic_forward, O.pqmf_classic_inverse)):
             m = rp.PQMF(attenuation=100, n_band=16, polyphase=poly)
             assert rel_l2(fa(x, hk), m(x)) < TOL and rel_l2(fs(y, hk), m.inverse(y)) < TOL
+
+
+def _sub(g, step, keep):
+    g = g.detach().reshape(-1)
+    return g if g.numel() <= keep else g[::step]
+
+
+def test_oracle_reproduces_the_full_width_reference_golden(golden_dir):
+    """v2_wide.pt: the reference's own modules at CAPACITY 96 (oracle/make_golden.py:golden_v2_wide) -- outputs and
+    parameter gradients under stored cotangents.  Pins the oracle at the benchmarked width."""
+    g = _load(golden_dir, "v2_wide.pt")
+    cfg = O.v2_config(capacity=g["config"]["capacity"], latent_size=g["config"]["latent_size"])
+    sd = O.seeded_state_dict(g["shapes"], g["seed"])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    full = dict(leaves)
+    full.update({"pqmf." + k: v for k, v in O.pqmf_buffers(100, 16).items()})
+    out = O.rave_forward(g["x"], full, cfg, g["eps"])
+    for k in ("x_mb", "z_params", "y_mb", "y_raw"):
+        assert rel_l2(out[k], g[k]) < TOL, k
+    torch.autograd.backward([out["y_raw"], out["y_mb"], out["reg"]], [g["cot_y_raw"], g["cot_y_mb"], torch.ones(())])
+    assert len(g["grads"]) == 112
+    for k, gref in g["grads"].items():
+        got = _sub(leaves[k].grad, g["grad_step"], g["grad_keep"])
+        assert rel_l2(got, gref) < 1e-5, (k, rel_l2(got, gref))

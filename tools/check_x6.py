@@ -46,6 +46,9 @@ layers = [
     ("ragged up k4s2 C48->36 L129 B2",  48,  36,  129, 4, 2, 1, 1, 1, 1, 1, 2, 1),
     ("mpd k5s1 inner7 C32->64 H90 B2",  32,  64,   90, 5, 1, 1, 2, 2, 0, 1, 2, 7),
     ("mpd k5s4 inner3 C32->64 H300 B2", 32,  64,  300, 5, 4, 1, 2, 2, 0, 1, 2, 3),
+    ("descript k5s1 inner11 C1024 H74 B2", 1024, 1024,  74, 5, 1, 1, 2, 2, 0, 0, 2, 11),
+    ("descript k5s3 inner11 C512->1024 H221 B2", 512, 1024, 221, 5, 3, 1, 2, 2, 0, 0, 2, 11),
+    ("descript k5s3 inner2 C128->512 H3641 B2", 128, 512, 3641, 5, 3, 1, 2, 2, 0, 0, 2, 2),
 ]
 sel = os.environ.get("ONLY")
 s = torch.cuda.current_stream().cuda_stream
