@@ -10,7 +10,8 @@ minibatch already resident in HBM: PQMF analysis -> EncoderV2 -> reparametrize -
 PQMF synthesis -> multi-scale STFT losses -> backward -> Adam.  Default workload = BASELINE.json
 configs[1]: v2, batch 32 mono, 44.1 kHz, n_signal 65536, VAE phase.  Multi-GPU: weak scaling, the
 minibatch is sharded (32 clips per GPU), gradients averaged with bucketed RCCL all-reduce
-overlapped with backward.  Rank 0 prints ONE JSON line.
+overlapped with backward.  Rank 0 prints ONE JSON line.  ``--gpus N`` without a torchrun environment
+re-launches itself under ``torch.distributed.run`` with N ranks (and fails if fewer GPUs are visible).
 """
 import argparse
 import json
@@ -30,56 +31,74 @@ V2_FWD_ACT_BYTES_PER_CLIP = 83_673_088
 V2_WEIGHT_BYTES = 126_123_072
 HBM_PEAK = 8.0e12          # B/s   MI355X_MICROARCH.md chip-level parameters
 F32_MFMA_PEAK = 157.3e12   # FLOP/s (f32-input MFMA == f32 vector peak)
+X6_MFMA_PEAK = 2.5e15 / 6  # FLOP/s f32-equivalent of the bf16 matrix cores at 6 MFMAs per product block (conv_x6)
 
 
-def cpu_baseline(n_signal: int, budget_s: float = 25.0):
-    """The oracle (CPU fp32 ATen restatement of the reference, oracle/rave_oracle.py) timed on this
-    box's host cores on a bounded sample of the same workload (v2 VAE-phase step)."""
+def cpu_baseline(n_signal: int, budget_s: float = 28.0):
+    """The oracle (CPU fp32 ATen restatement of the reference, oracle/rave_oracle.py -- bit-pinned to the reference
+    modules, tests/test_oracle.py) timed on this box's host cores on a bounded sample of the same workload:
+    (1) the metric's unit of work, the v2 VAE-phase training step, batch 8 on every host core;
+    (2) BASELINE configs[0] as worded: v2_small, 1 mono clip, forward + loss only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rave_oracle as O
+    nproc = os.cpu_count() or 1
+    t_start = time.perf_counter()
+    torch.set_num_threads(nproc)
+
+    def median(fn, max_n, budget):
+        fn()                                         # warm-up (oneDNN primitive creation)
+        times = []
+        t0 = time.perf_counter()
+        while len(times) < max_n and (not times or time.perf_counter() - t0 < budget):
+            t = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t)
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    # (2) configs[0]: v2_small forward + loss, one clip
+    cs = O.v2_small_config()
+    sds = O.init_state_dict(cs, seed=0, with_discriminator=False)
+    xs = O.synthetic_batch(1, 1, n_signal)
+    eps_s = torch.randn(1, cs.latent_size, n_signal // (cs.n_band * int(torch.tensor(cs.ratios).prod())))
+
+    def small_fwd():
+        with torch.no_grad():
+            O.generator_losses(xs, sds, cs, eps_s, warmed_up=False)
+
+    try:
+        t_small, n_small = median(small_fwd, 5, 4.0)
+        small = {"value": n_signal / t_small, "unit": "samples/s", "ms": 1e3 * t_small,
+                 "sample": f"BASELINE configs[0]: v2_small, 1 mono clip x {n_signal}, forward + loss, no_grad, "
+                           f"median of {n_small}, {nproc} threads"}
+    except Exception as e:   # the headline never depends on the auxiliary baseline
+        small = {"error": repr(e)}
+
+    # (1) v2 VAE-phase training step, batch 8
     cfg = O.v2_config()
     sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()
-              if k.startswith(("encoder.", "decoder."))}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(("encoder.", "decoder."))}
     full = dict(sd)
     full.update(leaves)
     opt = torch.optim.Adam(list(leaves.values()), 1e-3, (.5, .9))
-    b = 1
+    b = 8
     x = O.synthetic_batch(b, 1, n_signal)
     eps = torch.randn(b, cfg.latent_size, n_signal // 2048)
 
     def one():
-        t0 = time.perf_counter()
         opt.zero_grad()
         xx = x.clone().requires_grad_(True)
         loss, _, _, _ = O.generator_losses(xx, full, cfg, eps, warmed_up=False)
         loss.backward()
         opt.step()
-        return time.perf_counter() - t0
 
-    # one clip cannot feed every core of a big host: try two moderate thread counts, keep the best
-    nproc = os.cpu_count() or 1
-    t_start = time.perf_counter()
-    best_t, best_n = None, None
-    for n in sorted({min(nproc, 32), min(nproc, 16)}, reverse=True):
-        torch.set_num_threads(n)
-        one()                                   # warm-up (oneDNN primitive creation)
-        dt = one()
-        if best_t is None or dt < best_t:
-            best_t, best_n = dt, n
-        if time.perf_counter() - t_start > budget_s:
-            break
-    torch.set_num_threads(best_n)
-    times = [best_t]
-    while len(times) < 5 and time.perf_counter() - t_start < budget_s:
-        times.append(one())
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": b * n_signal / med, "unit": "samples/s", "cores": best_n, "host_cores": nproc,
-            "kind": "port",
-            "sample": f"v2 VAE-phase training step (fwd+losses+bwd+Adam), {b} clip x {n_signal} samples, "
-                      f"median of {len(times)} steps, best of torch thread counts 32/16 ({best_n}), "
-                      f"torch CPU fp32 oracle (oracle/rave_oracle.py); bounded to ~{budget_s:.0f} s"}
+    med, n = median(one, 5, max(4.0, budget_s - (time.perf_counter() - t_start) - 4.0))
+    return {"value": b * n_signal / med, "unit": "samples/s", "cores": nproc, "host_cores": nproc, "kind": "port",
+            "ms_per_step": 1e3 * med,
+            "sample": f"v2 VAE-phase training step (fwd+losses+bwd+Adam), {b} clips x {n_signal} samples, median of {n} "
+                      f"steps, {nproc} torch threads, torch CPU fp32 oracle (oracle/rave_oracle.py); bounded to "
+                      f"~{budget_s:.0f} s",
+            "v2_small_forward_loss": small}
 
 
 def main():
@@ -100,13 +119,29 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one process per GPU, launched here (never a silent single-rank run)
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} requested but only {torch.cuda.device_count()} GPU(s) visible")
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("RAVE_FORCE_DIST", "0") == "1"   # exercise the RCCL path with one rank
@@ -116,7 +151,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from rave_amd import ddp, model as M, ops
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
     torch.manual_seed(0)
     n_ch = 1
@@ -140,6 +174,8 @@ def main():
     use_ddp = world > 1 or force_dist
     red_gen = ddp.GradReducer(gen_params, force=force_dist) if use_ddp else None
     red_dis = ddp.GradReducer(list(m.discriminator.parameters()), force=force_dist) if use_ddp and m.warmed_up else None
+    # rank-0 buffers before every forward (torch DDP broadcast_buffers semantics): RVQ codebooks, BatchNorm stats
+    bufsync = ddp.BufferSync(m, force=force_dist) if use_ddp else None
 
     # synthetic 44.1 kHz waveforms, one shard per rank, resident in HBM
     g = torch.Generator().manual_seed(20250509 + rank)
@@ -152,12 +188,14 @@ def main():
 
     def step(i):
         if use_ddp:
+            bufsync.sync()
             dis_step = m.warmed_up and not (i % m.update_discriminator_every)
             red = red_dis if dis_step else red_gen
             red.begin()
             m.training_step(x.detach().clone(), i, grad_sync=lambda idx: red.finish())
         else:
             m.training_step(x.detach().clone(), i)
+        m.on_train_batch_end(None, None, i)       # generator LR schedule (rave/model.py:272-274)
 
     def fence():
         torch.cuda.synchronize()
@@ -168,11 +206,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    evs[0].record()
     for i in range(args.steps):
         step(args.warmup + i)
+        evs[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_ddp:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -190,6 +232,7 @@ def main():
                                + (" [opt-in: dead gradients skipped]" if args.skip_dead_grads else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "per_gpu_samples_per_s": samples / dt / world,
+        "ms_per_step_median_hip_events": per_step[len(per_step) // 2] if per_step else None,
     }
 
     if rank == 0 and not args.no_kernel_timing and args.config == "v2":
@@ -203,38 +246,41 @@ def main():
         for kind, fl, by, ms in rec:
             a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
-        # forward and data-gradient launches are the SAME kernel (conv_igemm_dma_kernel): group them
-        kernels = {"conv_x6_kernel + conv_igemm_dma_kernel (forward + data-gradient launches)": ["conv_fwd", "conv_dgrad"],
-                   "wgrad_dma_kernel (weight-gradient launches)": ["conv_wgrad"]}
-        ksum = {k: [sum(agg[f][i] for f in fams if f in agg) for i in range(4)] for k, fams in kernels.items()}
-        dom_name = max(ksum, key=lambda k: ksum[k][3])
-        dom = "conv_wgrad" if "wgrad" in dom_name else "conv_fwd"
-        n, fl, by, ms = ksum[dom_name]
-        # HBM traffic per launch of that kernel family from the committed rocprofv3 PMC passes
-        # (FETCH_SIZE / WRITE_SIZE collected in separate runs; see profiles/round1_pmc_traffic.json)
-        traffic, traffic_note = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            fam = "conv_wgrad" if dom == "conv_wgrad" else "conv_igemm(fwd+dgrad)"
-            if args.phase == "vae" and args.batch == 32 and args.n_signal == 65536:
-                traffic = pmc[fam]["hbm_bytes_per_launch"]
-                traffic_note = pmc["_provenance"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # every launch is priced against the peak of the instruction it issues: conv_x6_kernel = exact f32 as six
+        # v_mfma_f32_32x32x16_bf16 per product block (2.5 PF / 6 = 417 TFLOP/s f32-equivalent); the f32-input MFMA
+        # kernels (conv_igemm_dma_kernel forward / data gradient of the few geometries x6 does not take, and
+        # wgrad_dma_kernel) = 157.3 TFLOP/s
+        peak_of = lambda k: X6_MFMA_PEAK if k.endswith("[x6]") else F32_MFMA_PEAK
+        kern_of = {"conv_fwd[x6]": "conv_x6_kernel", "conv_dgrad[x6]": "conv_x6_kernel",
+                   "conv_fwd[f32]": "conv_igemm_dma_kernel", "conv_dgrad[f32]": "conv_igemm_dma_kernel",
+                   "conv_wgrad": "wgrad_dma_kernel"}
+        byk = {}
+        for k, v in agg.items():
+            a = byk.setdefault(kern_of.get(k, k), [0, 0.0, 0.0, 0.0, peak_of(k)])
+            for i in range(4):
+                a[i] += v[i]
+        dom_name = max(byk, key=lambda k: byk[k][3])
+        n, fl, by, ms, peak = byk[dom_name]
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom_name,
-            "achieved": fl / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": fl / (ms * 1e-3) / F32_MFMA_PEAK, "traffic": traffic, "traffic_unit": "B per launch",
-            "algorithmic_bytes_per_launch": by / n, "traffic_note": traffic_note,
+            "bound": "mfma", "kernel": dom_name + (" (forward + data-gradient launches)" if dom_name != "wgrad_dma_kernel"
+                                                   else " (weight-gradient launches)"),
+            "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": fl / (ms * 1e-3) / peak, "frac_vs_exact_f32_peak": fl / (ms * 1e-3) / F32_MFMA_PEAK,
+            "traffic": None,
+            "traffic_note": "HBM bytes per launch are collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                            "passes (tools/pmc_traffic.sh) and kept under profiles/ (round2_pmc_traffic.json), not in "
+                            "this line: the counters cannot be read from inside the timed process",
+            "algorithmic_bytes_per_launch": by / n,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9,
-            "note": "f32 in / f32 accumulate; the stride-1 convolutions run conv_x6_kernel (every f32 split exactly into "
-                    "3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block: same numerics class, ceiling 2.5 PF / 6 = "
-                    "417 TFLOP/s f32-equivalent), the strided / transposed ones conv_igemm_dma_kernel "
-                    "(v_mfma_f32_32x32x2_f32, ceiling 157.3); peak = the exact-f32 MFMA peak; HIP events on the launch "
-                    "stream around every launch of the kernel family with the largest total time",
+            "note": "f32 in / f32 accumulate everywhere; peak = that of the instruction the kernel issues (conv_x6_kernel: "
+                    "every f32 split exactly into 3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block -> 2.5 PF / 6 = "
+                    "417 TFLOP/s f32-equivalent; f32-input MFMA kernels: 157.3); HIP events on the launch stream around "
+                    "every launch of the kernel with the largest total time",
         }
+        out["kernels"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
+                              "tflops": v[1] / (v[3] * 1e-3) / 1e12, "peak_tflops": v[4] / 1e12,
+                              "frac_of_issued_peak": v[1] / (v[3] * 1e-3) / v[4]} for k, v in byk.items()}
         out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
                                       "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}
@@ -265,8 +311,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "v2":
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
     if use_ddp:
-        out["ddp"] = {"allreduce_bytes_per_step": (red_gen.bytes_reduced + (red_dis.bytes_reduced if red_dis else 0))
-                      // max(args.warmup + args.steps, 1), "buckets": len(red_gen.buckets), "backend": "nccl (RCCL)"}
+        tot = red_gen.bytes_reduced + (red_dis.bytes_reduced if red_dis else 0)
+        ovl = red_gen.bytes_overlapped + (red_dis.bytes_overlapped if red_dis else 0)
+        nst = max(args.warmup + args.steps, 1)
+        out["ddp"] = {"allreduce_bytes_per_step": tot // nst, "buckets": len(red_gen.buckets), "backend": "nccl (RCCL)",
+                      "bytes_issued_before_backward_ended_per_step": ovl // nst,
+                      "overlap_fraction": ovl / tot if tot else None,
+                      "buffer_broadcast_bytes_per_step": bufsync.bytes_sent // nst}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

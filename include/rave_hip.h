@@ -137,6 +137,11 @@ int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_f
  * legal: the launch then runs unsplit (slower, same accumulation class). */
 int64_t rh_conv1d_fwd_workspace_bytes(const rh_conv1d_desc* d);
 int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d);
+/* Which kernel family rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32 (which = 1) would launch for this
+ * geometry and operand set: 1 = exact f32 on the bf16 matrix cores (3-way split, conv_x6_kernel), 0 = f32-input MFMA
+ * kernels, < 0 = invalid descriptor.  Measurement only (bench.py prices every launch against the peak of the
+ * instruction it issues); has_bias / has_add = the optional operands are non-NULL. */
+int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add);
 
 /* dx = act'(x) * conv_bwd_data(dy) + add.   `x` is the forward input (needed when act != NONE),
  * `add` (B,c_in,l_in*inner) may be NULL (residual-branch gradient). */

@@ -519,6 +519,18 @@ extern "C" int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d) {
     return rh_conv_splitk_workspace(p);
 }
 
+extern "C" int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add) {
+    ConvP p{};
+    if (int e = which == 0 ? rh_conv_fill_fwd(d, &p) : rh_conv_fill_dgrad(d, &p)) return e;
+    alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};     // only tested against NULL / alignment by the planner
+    p.in = dummy; p.wp = dummy; p.wq = reinterpret_cast<const unsigned*>(dummy);
+    p.bias = has_bias ? dummy : nullptr;
+    p.add = has_add ? dummy : nullptr;
+    p.mul_src = (which == 1 && d->act != RH_ACT_NONE) ? dummy : nullptr;
+    if (p.B <= 0 || p.ncols <= 0 || p.M <= 0 || !rh_conv_dma_eligible(p)) return 0;
+    return rh_conv_x6_workspace(p) >= 0 ? 1 : 0;
+}
+
 extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_fwd,
                                  const float* bias, const float* snake_alpha, const float* residual,
                                  float* y, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {

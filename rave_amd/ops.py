@@ -45,9 +45,12 @@ def _conv_cost(d: "L.ConvDesc"):
     return flops, 4.0 * (x_elems + y_elems + w_elems)
 
 
-def _launch(kind: str, d, fn):
+def _launch(kind: str, d, fn, has_bias=False, has_add=False):
     if _PROFILE is None:
         return fn()
+    if kind in ("conv_fwd", "conv_dgrad"):   # which instruction does this launch issue?
+        fam = L.lib.rh_conv1d_kernel_family(C.byref(d), 0 if kind == "conv_fwd" else 1, int(has_bias), int(has_add))
+        kind += "[x6]" if fam == 1 else "[f32]"
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -104,14 +107,14 @@ def _fwd(d, x, wp, bias, alpha, residual, y, s):
     ws = _ws(L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)), y.device)
     return _launch("conv_fwd", d, lambda: L.lib.rh_conv1d_fwd_f32(
         C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y),
-        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s))
+        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s), bias is not None, residual is not None)
 
 
 def _dgrad(d, dy, wp, x, alpha, add, dx, s):
     ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
     return _launch("conv_dgrad", d, lambda: L.lib.rh_conv1d_bwd_data_f32(
         C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(dx),
-        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s))
+        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s), False, add is not None)
 
 
 def _shapes(x: Tensor, weight: Tensor, g: ConvGeom):
