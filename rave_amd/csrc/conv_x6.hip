@@ -63,8 +63,13 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     pl->row_tiles = rh_cdiv(p.Mp, BM);
     const int blocks = pl->col_tiles * pl->row_tiles * p.nphase;
     const int total_chunks = (p.C * is) >> 4;
-    static const int split_below = [] { const char* e = getenv("RH_X6_SPLIT_BELOW"); return e ? atoi(e) : 384; }();
+    // K is split across workgroups when the output tiles alone cannot fill 256 CUs x 2.  Measured (layer table,
+    // profiles/): 256-tile launches run faster UNSPLIT when the epilogue is a plain store (no partial sums to write and
+    // re-read, no finalize launch), but slower when the epilogue reads the saved input for the activation derivative
+    // (one round of workgroups exposes those loads; the finalize pass streams them) -- hence two thresholds.
+    static const int split_env = [] { const char* e = getenv("RH_X6_SPLIT_BELOW"); return e ? atoi(e) : 0; }();
     static const int split_target = [] { const char* e = getenv("RH_X6_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    const int split_below = split_env > 0 ? split_env : (p.epi_act != RH_ACT_NONE ? 384 : 200);
     int z = 1;
     if (blocks < split_below) {
         z = rh_cdiv(split_target, blocks);
