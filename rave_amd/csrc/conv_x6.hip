@@ -2,9 +2,9 @@
 #include <cstdlib>
 #include "conv_params.hpp"
 
-void rh_x6_dispatch_is1(const ConvP& q, int tm, int wm, dim3 grid, size_t lds, hipStream_t stream);
-void rh_x6_dispatch_is2(const ConvP& q, int tm, int wm, dim3 grid, size_t lds, hipStream_t stream);
-void rh_x6_dispatch_is4(const ConvP& q, int tm, int wm, dim3 grid, size_t lds, hipStream_t stream);
+void rh_x6_dispatch_is1(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
+void rh_x6_dispatch_is2(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
+void rh_x6_dispatch_is4(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
 int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream);
 
 namespace {
@@ -12,7 +12,7 @@ namespace {
 struct X6Plan {
     size_t lds;
     int64_t part_bytes;
-    int tm, wm, wn, ksplit, chunks_per_split, col_tiles, row_tiles;
+    int tm, tn, wm, wn, ksplit, chunks_per_split, col_tiles, row_tiles;
 };
 
 bool x6_enabled() {
@@ -32,18 +32,6 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     if (((uintptr_t)p.wq & 15) || ((uintptr_t)p.in & 3)) return false;
     const int is = p.is;
     pl->tm = p.Mp % 96 == 0 ? 3 : (p.Mp % 64 == 0 ? 2 : 1);
-    pl->wm = p.Mp >= 64 * pl->tm ? 2 : 1;
-    pl->wn = 4 / pl->wm;
-    const int BM = 32 * pl->tm * pl->wm, BN = 64 * pl->wn;
-    int bnl = BN;
-    if (p.ncols < BN) {
-        bnl = 32;
-        while (bnl < p.ncols) bnl <<= 1;
-    }
-    p.bnl = bnl;
-    p.bnl_shift = __builtin_ctz(bnl);
-    p.nb = BN / bnl;
-    p.tiles_per_b = rh_cdiv(p.ncols, bnl);
     int span = 0;
     if (is == 1) {
         for (int i = 0; i < p.nphase; ++i) span = span > p.ph_maxoff[i] - p.ph_minoff[i] ? span : p.ph_maxoff[i] - p.ph_minoff[i];
@@ -51,17 +39,46 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     } else {
         span = p.x6_nu - 1;
     }
-    p.pitch = bnl + span;
-    p.x6_P = p.nb * p.pitch;
-    const int nq = pl->wn == 4 ? 3 : 2;
-    if (2 * p.x6_P > 256 * nq) return false;
-    p.x6_a_units = 6 * BM;
-    p.x6_b_units = 6 * p.x6_P;
-    pl->lds = (size_t)(2 * p.x6_a_units + 2 * p.x6_b_units) * 16;
-    if (pl->lds > 160 * 1024) return false;
-    pl->col_tiles = rh_cdiv(p.B, p.nb) * p.tiles_per_b;
-    pl->row_tiles = rh_cdiv(p.Mp, BM);
-    const int blocks = pl->col_tiles * pl->row_tiles * p.nphase;
+    // Workgroup tile = (32*tm*wm) rows x (32*tn*wn) columns, wm*wn = 4 waves, wave tile 32*tm x 32*tn.  Two waves of
+    // rows when the layer has them; the 64-column wave tile (half the A-fragment reads per MFMA) unless that leaves
+    // fewer than ~1.5 workgroups per CU -- then the 32-column one doubles the number of tiles, which beats splitting K
+    // (partial sums written and re-read + a finalize launch; measured on the C = 192 ... 768 layers).
+    auto shape = [&](int tn, int wm) -> int {        // fills the tile fields of p; returns the number of tiles (0 = does not fit)
+        pl->tn = tn; pl->wm = wm; pl->wn = 4 / wm;
+        const int BM = 32 * pl->tm * wm, BN = 32 * tn * pl->wn;
+        int bnl = BN;
+        if (p.ncols < BN) {
+            bnl = 32;
+            while (bnl < p.ncols) bnl <<= 1;
+        }
+        p.bnl = bnl;
+        p.bnl_shift = __builtin_ctz(bnl);
+        p.nb = BN / bnl;
+        p.tiles_per_b = rh_cdiv(p.ncols, bnl);
+        p.pitch = bnl + span;
+        p.x6_P = p.nb * p.pitch;
+        const int nq = pl->wn * tn == 8 ? 3 : 2;
+        if (2 * p.x6_P > 256 * nq) return 0;
+        p.x6_a_units = 6 * BM;
+        p.x6_b_units = 6 * p.x6_P;
+        pl->lds = (size_t)(2 * p.x6_a_units + 2 * p.x6_b_units) * 16;
+        if (pl->lds > 160 * 1024) return 0;
+        pl->col_tiles = rh_cdiv(p.B, p.nb) * p.tiles_per_b;
+        pl->row_tiles = rh_cdiv(p.Mp, BM);
+        return pl->col_tiles * pl->row_tiles * p.nphase;
+    };
+    const int wm0 = p.Mp >= 64 * pl->tm ? 2 : 1;
+    static const int tn_env = [] { const char* e = getenv("RH_X6_TN"); return e ? atoi(e) : 0; }();
+    int blocks = shape(2, wm0);
+    // ... for the short reductions only (pointwise and k = 3 convs at few channels: <= 64 steps): with a long K loop
+    // per tile the split's fixed cost is small and the larger wave tile wins (measured per layer, profiles/)
+    const int total_steps = ((p.C * is) >> 4) * (is == 1 ? p.ph_ntaps[0] : p.x6_nu);
+    if (pl->tm >= 2 && (tn_env == 1 || (tn_env == 0 && blocks < 384 && total_steps <= 64))) {
+        const int b1 = shape(1, wm0);
+        if (b1 == 0) blocks = shape(2, wm0);
+        else blocks = b1;
+    }
+    if (blocks == 0) return false;
     const int total_chunks = (p.C * is) >> 4;
     // K is split across workgroups when the output tiles alone cannot fill 256 CUs x 2.  Measured (layer table,
     // profiles/): 256-tile launches run faster UNSPLIT when the epilogue is a plain store (no partial sums to write and
@@ -113,9 +130,9 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;
     dim3 grid(pl.col_tiles, pl.row_tiles, q.nphase * q.ksplit);
-    if (q.is == 1) rh_x6_dispatch_is1(q, pl.tm, pl.wm, grid, pl.lds, stream);
-    else if (q.is == 2) rh_x6_dispatch_is2(q, pl.tm, pl.wm, grid, pl.lds, stream);
-    else rh_x6_dispatch_is4(q, pl.tm, pl.wm, grid, pl.lds, stream);
+    if (q.is == 1) rh_x6_dispatch_is1(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
+    else if (q.is == 2) rh_x6_dispatch_is2(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
+    else rh_x6_dispatch_is4(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     if (int e = rh_check_launch(what)) return e;
     *used = true;
     if (q.ksplit > 1) return rh_splitk_finalize_launch(q, stream);

@@ -4,6 +4,6 @@
 #include "conv_params.hpp"
 #include "conv_x6_kernel.inc"
 
-void rh_x6_dispatch_is2(const ConvP& q, int tm, int wm, dim3 grid, size_t lds, hipStream_t stream) {
-    x6_dispatch<2>(q, tm, wm, grid, lds, stream);
+void rh_x6_dispatch_is2(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream) {
+    x6_dispatch<2>(q, tm, tn, wm, grid, lds, stream);
 }
