@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--skip-dead-grads", action="store_true",
                     help="opt-in (NOT the headline): skip gradients the reference computes and discards "
                          "(rave_amd.model.RAVE.skip_dead_grads)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run the eager step instead of replaying the captured hipGraph (single-GPU runs only; "
+                         "data-parallel runs are always eager: the collectives are issued from autograd hooks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -191,11 +194,12 @@ def main():
         # explicitly so that rave/quantization.py is exercised; the k-means init runs in the warm-up steps
         m.encoder.enabled.fill_(1)
     ddp.broadcast_module(m)
-    gen_opt, dis_opt = m.configure_optimizers()
+    use_ddp = world > 1 or force_dist
+    use_graph = not args.no_graph and not use_ddp
+    gen_opt, dis_opt = m.configure_optimizers(capturable=use_graph)
     m.warmed_up = args.phase == "gan"
     m.skip_dead_grads = bool(args.skip_dead_grads)
     gen_params = list(m.encoder.parameters()) + list(m.decoder.parameters())
-    use_ddp = world > 1 or force_dist
     red_gen = ddp.GradReducer(gen_params, force=force_dist) if use_ddp else None
     red_dis = ddp.GradReducer(list(m.discriminator.parameters()), force=force_dist) if use_ddp and m.warmed_up else None
     # rank-0 buffers before every forward (torch DDP broadcast_buffers semantics): RVQ codebooks, BatchNorm stats
@@ -210,15 +214,19 @@ def main():
         x = x + a * torch.sin(6.283185307 * f0 * t + ph)
     x = x.clamp(-1, 1).to(dev)
 
-    def step(i):
-        if use_ddp:
+    graphed = M.GraphedTrainingStep(m, x) if use_graph else None
+
+    def step(i, eager=False):
+        if graphed is not None and not eager:
+            graphed(x, i)
+        elif use_ddp:
             bufsync.sync()
             dis_step = m.warmed_up and not (i % m.update_discriminator_every)
             red = red_dis if dis_step else red_gen
             red.begin()
             m.training_step(x.detach().clone(), i, grad_sync=lambda idx: red.finish())
         else:
-            m.training_step(x.detach().clone(), i)
+            m.training_step(x.detach().clone(), i, capture_safe=use_graph)
         m.on_train_batch_end(None, None, i)       # generator LR schedule (rave/model.py:272-274)
 
     def fence():
@@ -257,6 +265,7 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}"},
         "per_gpu_samples_per_s": samples / dt / world,
         "ms_per_step_median_hip_events": per_step[len(per_step) // 2] if per_step else None,
+        "step_mode": "hipGraph replay (rave_amd.model.GraphedTrainingStep)" if use_graph else "eager",
     }
 
     if rank == 0 and not args.no_kernel_timing and args.config == "v2":
@@ -264,7 +273,7 @@ def main():
         reps = 2
         ops.profile_begin()
         for i in range(reps):
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + i, eager=True)     # per-launch events need the eager step
         rec = ops.profile_end()
         agg = {}
         for kind, fl, by, ms in rec:

@@ -60,6 +60,25 @@ def normalization(module: nn.Module, mode: Optional[str] = None):
     raise Exception(f"Normalization mode {mode} not supported")
 
 
+
+def _set_warmed_up(mod, state: bool) -> None:
+    """rave/blocks.py:736-738 re-creates the ``warmed_up`` buffer from a host scalar on every training step (a
+    host-to-device copy) and ``forward`` branches on it (a device-to-host sync).  Same
+    buffer and state_dict here, but the value is shadowed on the host and the buffer is only rewritten -- in place --
+    when it changes: no copy, no sync in the steady state, and the step can be recorded into a hipGraph."""
+    state = bool(state)
+    if getattr(mod, "_warmed_up_host", None) != state:
+        mod._warmed_up_host = state
+        mod.warmed_up.fill_(int(state))
+
+
+def _is_warmed_up(mod) -> bool:
+    h = getattr(mod, "_warmed_up_host", None)
+    if h is None:          # never set through set_warmed_up (e.g. right after load_state_dict): read the buffer once
+        h = mod._warmed_up_host = bool(mod.warmed_up)
+    return h
+
+
 class Snake(nn.Module):
     """rave/blocks.py:852-860 on the HIP Snake kernels (forward, dx and the per-channel dalpha
     reduction).  Inference-only graphs may instead fuse it into the next conv (ACT_SNAKE)."""
@@ -384,12 +403,11 @@ class VariationalEncoder(nn.Module):
         return z, self.beta * kl
 
     def set_warmed_up(self, state: bool):
-        state = torch.tensor(int(state), device=self.warmed_up.device)
-        self.warmed_up = state
+        _set_warmed_up(self, state)
 
     def forward(self, x: torch.Tensor):
         z = self.encoder(x)
-        if self.warmed_up:
+        if _is_warmed_up(self):
             z = z.detach()
         return z
 
@@ -421,12 +439,11 @@ class WasserteinEncoder(nn.Module):
         return z, reg.mean()
 
     def set_warmed_up(self, state: bool):
-        state = torch.tensor(int(state), device=self.warmed_up.device)
-        self.warmed_up = state
+        _set_warmed_up(self, state)
 
     def forward(self, x: torch.Tensor):
         z = self.encoder(x)
-        if self.warmed_up:
+        if _is_warmed_up(self):
             z = z.detach()
         return z
 
@@ -483,8 +500,7 @@ class DiscreteEncoder(nn.Module):
         return z, diff
 
     def set_warmed_up(self, state: bool):
-        state = torch.tensor(int(state), device=self.warmed_up.device)
-        self.warmed_up = state
+        _set_warmed_up(self, state)
 
     def forward(self, x):
         return self.encoder(x)
@@ -621,8 +637,7 @@ class Generator(nn.Module):
         self.register_buffer("warmed_up", torch.tensor(0))
 
     def set_warmed_up(self, state: bool):
-        state = torch.tensor(int(state), device=self.warmed_up.device)
-        self.warmed_up = state
+        _set_warmed_up(self, state)
 
     def forward(self, x, noise: Optional[torch.Tensor] = None):
         x = self.net(x)
@@ -632,7 +647,7 @@ class Generator(nn.Module):
             loudness = loudness.repeat_interleave(self.loud_stride)
         loudness = loudness.reshape(x.shape[0], 1, -1)
         waveform = torch.tanh(waveform) * mod_sigmoid(loudness)
-        if self.warmed_up and self.use_noise:
+        if _is_warmed_up(self) and self.use_noise:
             waveform = waveform + br[2](x, noise=noise)
         return waveform
 

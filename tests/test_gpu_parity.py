@@ -1235,3 +1235,40 @@ def test_full_width_descript_discriminator_step_vs_oracle(dev):
     xy = torch.cat([O.synthetic_batch(1, 2, 65536, seed=45), O.synthetic_batch(1, 2, 65536, seed=46) * 0.7], 0)
     _hinge_step_vs_oracle(dev, model, lambda x, sd: O.descript_discriminator(
         x, {"d." + k: v for k, v in sd.items()}, "d", periods, ffts), xy)
+
+
+def test_graphed_training_step_is_bit_identical_to_eager(dev):
+    """rave_amd.model.GraphedTrainingStep (the whole step as one hipGraph replay) vs the eager training_step: same
+    kernels in the same order, so parameters must be BIT-identical after 8 steps (VAE phase, injected noise)."""
+    from rave_amd import model as M
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = M.build_v2(capacity=16, latent_size=16).to(dev).train()
+        m.configure_optimizers(capturable=True)
+        xs = [O.synthetic_batch(2, 1, 32768, seed=50 + i).to(dev) for i in range(8)]
+        gen = torch.Generator().manual_seed(2)
+        es = [torch.randn(2, 16, 16, generator=gen).to(dev) for _ in range(8)]
+        step = M.GraphedTrainingStep(m, xs[0], inject_eps=True) if graphed else None
+        for i in range(8):
+            if graphed:
+                step(xs[i], i, eps=es[i])
+            else:
+                m.training_step(xs[i].clone(), i, eps=es[i], capture_safe=True)
+            m.on_train_batch_end(None, None, i)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in m.named_parameters()}, (step.logged if graphed else m.logged)
+
+    pe, le = run(False)
+    pg, lg = run(True)
+    moved = 0
+    for k in pe:
+        assert torch.equal(pe[k], pg[k]), k
+    torch.manual_seed(0)
+    m0 = M.build_v2(capacity=16, latent_size=16)
+    for k, v in m0.named_parameters():
+        if k.startswith(("encoder.", "decoder.")) and not torch.equal(v.detach(), pe[k].cpu()):
+            moved += 1
+    assert moved > 50                      # the optimizer really ran
+    for k in ("fullband_spectral_distance", "multiband_spectral_distance", "regularization"):
+        assert torch.equal(le[k].detach(), lg[k].detach()), k
