@@ -570,11 +570,18 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
 
 }  // namespace
 
+int64_t rh_wgrad_x6_workspace(const WgradP& w);
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, void* ws, hipStream_t stream, bool* used);
+
 int64_t rh_wgrad_workspace(const rh_conv1d_desc* d) {
     WgradP p{};
     fill(d, &p);
-    const WPlan w = plan(p);
     const int64_t bias = rh_bias_grad_workspace(d->c_out);
+    if (d->act != RH_ACT_SNAKE) {      // exact f32 on the bf16 matrix cores (conv_wgrad_x6.hip) when the geometry fits
+        const int64_t x6 = rh_wgrad_x6_workspace(p);
+        if (x6 >= 0) return bias + x6;
+    }
+    const WPlan w = plan(p);
     if (w.Z <= 1) return bias;
     return bias + (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float);
 }
@@ -601,6 +608,16 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
         (void)hipMemsetAsync(dw, 0, nw * sizeof(float), stream);
         if (dbias) (void)hipMemsetAsync(dbias, 0, d->c_out * sizeof(float), stream);
         return RH_OK;
+    }
+    if (d->act != RH_ACT_SNAKE) {
+        const int64_t x6 = rh_wgrad_x6_workspace(p);
+        if (x6 >= 0) {
+            RH_REQUIRE(x6 == 0 || (ws && ws_bytes >= x6), RH_ERR_WORKSPACE,
+                       "conv1d_bwd_weight: workspace %lld B < %lld B", (long long)ws_bytes, (long long)x6);
+            bool used = false;
+            if (int e = rh_wgrad_x6_launch(p, dw, ws, stream, &used)) return e;
+            if (used) return RH_OK;
+        }
     }
     const WPlan w = plan(p);
     const int64_t need = w.Z > 1 ? (int64_t)w.Z * nw * (int64_t)sizeof(float) : 0;

@@ -1,0 +1,300 @@
+// Weight gradient of the 1-D convolutions, exact f32 on the bf16 matrix cores ("x6", see conv_x6_kernel.inc for the
+// numerics: 3-way exact bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per product block, smallest terms
+// first):
+//   out[z][m][c*T + t] = sum_{(b,n) in K slice z} actR(R[b][m][n]) * actS(S[b][c][n*is + off[t]])
+// (conv_params.hpp: WgradP; R = dy, S = x for Conv1d, the roles swap for ConvTranspose1d).
+//
+// GEMM view: rows m, columns (c, t), reduction over POSITIONS -- the contiguous axis of both operands.  A 16-deep MFMA
+// k block is 16 consecutive positions of one batch item, and lane (j, g)'s fragment is 8 consecutive samples of one
+// row: no transposition anywhere, every thread converts whole fragments.  Per step (16 positions):
+//   * every thread owns (row, half) tasks of the R tile and (column, half) tasks of the S tile: it loads the 8 samples
+//     straight from HBM/L2 one step ahead (buffer loads: padding and ragged tails read 0.0), applies LeakyReLU, splits
+//     exactly and writes three 16-byte fragments [g][piece][row] to the other LDS stage;
+//   * wave tile 32*TM x 64, fragments by ds_read_b128, 12*TM MFMAs per step and wave, one barrier per step.
+// Both operands need the conversion (the forward kernel gets its weights pre-split), ~4 VALU instructions per MFMA, so
+// this kernel lives off the overlap of one workgroup's conversion with the other's MFMAs (2 workgroups per CU).
+// K is split over (batch, position) ranges; the partial sums are combined in slice order by reduce_partials_kernel.
+#include <cstdlib>
+#include <mutex>
+#include "conv_params.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;
+
+struct Wx6P {
+    const float* R;
+    const float* S;
+    float* out;                 // [Z][M][N] partials (or dw itself when Z == 1)
+    int B, M, C, T, N;          // N = C * T
+    int r_row, s_row, s_valid, is;
+    float r_slope, s_slope;     // LeakyReLU slope of the operand's activation; 1 = none
+    int steps_per_b;            // ceil(r_row / 16)
+    int total_steps, steps_per_z;
+    unsigned r_bytes, s_bytes;
+    int minoff, maxoff;
+    int off[kMaxTaps];
+};
+
+__device__ __forceinline__ void split3(float x, unsigned& a, unsigned& b, unsigned& c) {
+    a = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(a);
+    b = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b);
+    c = __float_as_uint(r2) & 0xffff0000u;
+}
+
+__device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* dst, int piece_stride) {
+    unsigned h[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float x = v[i];
+        x = x > 0.f ? x : x * slope;
+        split3(x, h[0][i], h[1][i], h[2][i]);
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        u32x4 pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
+        dst[s3 * piece_stride] = pk;
+    }
+}
+
+template <int TM, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = 32 * TM * WM, BN = 64 * WN;
+    constexpr int A_UNITS = 6 * BM, B_UNITS = 6 * BN;
+    constexpr int NA = (2 * BM + 255) / 256, NB = (2 * BN + 255) / 256;      // tasks per thread and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* const a_st = reinterpret_cast<u32x4*>(smem_raw);
+    u32x4* const b_st = a_st + 2 * A_UNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
+    const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.S), 0, p.s_bytes, 0x00020000);
+
+    // ---- tasks (chunk-invariant): row part of the element offset, fragment slot in the stage, tap offset
+    unsigned aoff[NA], boff[NB];
+    int adst[NA], bdst[NB], ag8[NA], bp0[NB];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        const int u = tid + 256 * q;
+        const int gg = u / BM, m = u - gg * BM;
+        const bool ok = u < 2 * BM && m0 + m < p.M;
+        adst[q] = u < 2 * BM ? gg * 3 * BM + m : -1;
+        ag8[q] = 8 * gg;
+        aoff[q] = ok ? (unsigned)(((m0 + m) * p.r_row + 8 * gg) * 4) : kOOB;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int u = tid + 256 * q;
+        const int gg = u / BN, col = u - gg * BN;
+        const int cc = (n0 + col) / p.T, t = (n0 + col) - cc * p.T;
+        const bool ok = u < 2 * BN && n0 + col < p.N;
+        bdst[q] = u < 2 * BN ? gg * 3 * BN + col : -1;
+        bp0[q] = 8 * gg * p.is + (ok ? p.off[t] : 0);                 // position of sample 0 relative to n * is
+        boff[q] = ok ? (unsigned)((cc * p.s_row + bp0[q]) * 4) : kOOB;
+    }
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    float ra[NA][8], rb[NB][8];
+    auto load = [&](int st) {
+        const int b = st / p.steps_per_b;
+        const int n = (st - b * p.steps_per_b) * 16;
+        const unsigned rs = (unsigned)((b * p.M * p.r_row + n) * 4);
+        const unsigned ss = (unsigned)((b * p.C * p.s_row + n * p.is) * 4);
+        const bool r_tail = n + 16 > p.r_row;                                      // uniform
+        const bool s_edge = n * p.is + p.minoff < 0 || (n + 15) * p.is + p.maxoff >= p.s_valid || r_tail;
+        // the whole element offset goes into the per-lane operand (the bounds check must see it: a tap offset alone
+        // can be negative for a valid sample), nothing into the scalar offset
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const unsigned base = aoff[q] == kOOB ? kOOB : aoff[q] + rs;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                unsigned off = base == kOOB ? kOOB : base + 4u * i;
+                if (r_tail) off = n + ag8[q] + i < p.r_row ? off : kOOB;
+                ra[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const unsigned base = boff[q] == kOOB ? kOOB : boff[q] + ss;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                unsigned off = base == kOOB ? kOOB : base + 4u * (unsigned)(i * p.is);
+                if (s_edge) {
+                    const int pos = n * p.is + bp0[q] + i * p.is;
+                    off = (pos >= 0 && pos < p.s_valid) ? off : kOOB;
+                }
+                rb[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rsrc, off, 0, 0));
+            }
+        }
+    };
+    auto convert = [&](int stage) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            if (adst[q] >= 0) emit(ra[q], p.r_slope, a_st + stage * A_UNITS + adst[q], BM);
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (bdst[q] >= 0) emit(rb[q], p.s_slope, b_st + stage * B_UNITS + bdst[q], BN);
+    };
+
+    const int st0 = z * p.steps_per_z;
+    const int nst = min(p.steps_per_z, p.total_steps - st0);
+    if (nst > 0) {
+        load(st0);
+        convert(0);
+    }
+    __syncthreads();
+    const int arow = g * 3 * BM + wm * TM * 32 + j;
+    const int bcol = g * 3 * BN + wn * 64 + j;
+    for (int s = 0; s < nst; ++s) {
+        const bool more = s + 1 < nst;
+        if (more) load(st0 + s + 1);
+        const u32x4* al = a_st + (s & 1) * A_UNITS + arow;
+        const u32x4* bl = b_st + (s & 1) * B_UNITS + bcol;
+        bf16x8 bfr[2][3], afr[TM][3];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+        constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn], 0, 0, 0);
+        if (more) convert((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- partial sums of this K slice
+    float* __restrict__ outz = p.out + (long)z * p.M * p.N;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wn * 64 + tn * 32 + j;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mb = m0 + (wm * TM + tm) * 32 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) outz[(long)m * p.N + col] = acc[tm][tn][r];
+            }
+        }
+    }
+}
+
+struct Wx6Plan {
+    int tm, wm, rt, ct, Z, steps_per_z;
+};
+
+bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
+    const char* e = getenv("RH_WGRAD_X6");        // read per call: the parity tests flip it at run time
+    if (e && atoi(e) == 0) return false;
+    if (w.inner != 1 || w.T > kMaxTaps || w.B <= 0 || w.r_row <= 0) return false;
+    if ((w.r_act != RH_ACT_NONE && w.r_act != RH_ACT_LEAKY) || (w.s_act != RH_ACT_NONE && w.s_act != RH_ACT_LEAKY)) return false;
+    if (w.M < 32 || (long)w.C * w.T < 64) return false;            // tiny GEMMs (first discriminator layers): f32 kernels
+    // Measured per layer (profiles/round2_layer_table_b32.txt): with one fragment = 8 samples of ONE row per lane, a
+    // wave's load instruction touches 64 different rows; that only pays when rows are short (the deep stages: 32 / 64
+    // positions, many channels -- 1.2x ... 2.1x over the f32-MFMA kernel there).  On long rows the LDS-DMA row segments
+    // of wgrad_dma_kernel are the better data path, and pointwise convs have too few columns per converted row.
+    static const int force = [] { const char* e2 = getenv("RH_WGRAD_X6_ALL"); return e2 ? atoi(e2) : 0; }();
+    if (!force && (w.r_row > 64 || w.T < 3)) return false;
+    const unsigned long long rb = 4ull * w.B * w.M * (unsigned long long)w.r_row;
+    const unsigned long long sb = 4ull * w.B * w.C * (unsigned long long)w.s_row;
+    if (rb >= 0x7fffffffull || sb >= 0x7fffffffull) return false;
+    *p = Wx6P{};
+    p->R = w.R; p->S = w.S;
+    p->B = w.B; p->M = w.M; p->C = w.C; p->T = w.T; p->N = w.C * w.T;
+    p->r_row = w.r_row; p->s_row = w.s_row; p->s_valid = w.s_valid; p->is = w.is;
+    p->r_slope = w.r_act == RH_ACT_LEAKY ? w.r_slope : 1.f;
+    p->s_slope = w.s_act == RH_ACT_LEAKY ? w.s_slope : 1.f;
+    p->steps_per_b = rh_cdiv(w.r_row, 16);
+    p->total_steps = w.B * p->steps_per_b;
+    p->r_bytes = (unsigned)rb; p->s_bytes = (unsigned)sb;
+    p->minoff = w.minoff; p->maxoff = w.maxoff;
+    for (int t = 0; t < w.T; ++t) p->off[t] = w.off[t];
+    const int Mp = (w.M + 31) & ~31;
+    pl->tm = Mp % 96 == 0 ? 3 : (Mp % 64 == 0 ? 2 : 1);
+    pl->wm = Mp >= 64 * pl->tm ? 2 : 1;
+    const int BM = 32 * pl->tm * pl->wm, BN = 64 * (4 / pl->wm);
+    pl->rt = rh_cdiv(w.M, BM);
+    pl->ct = rh_cdiv(p->N, BN);
+    static const int target = [] { const char* e2 = getenv("RH_WGRAD_X6_BLOCKS"); return e2 ? atoi(e2) : 1024; }();
+    int Z = rh_cdiv(target, pl->rt * pl->ct);
+    const int zmax = p->total_steps / 8 > 0 ? p->total_steps / 8 : 1;     // at least 8 steps (128 positions) per slice
+    if (Z > zmax) Z = zmax;
+    if (Z < 1) Z = 1;
+    pl->steps_per_z = rh_cdiv(p->total_steps, Z);
+    pl->Z = rh_cdiv(p->total_steps, pl->steps_per_z);
+    p->steps_per_z = pl->steps_per_z;
+    return true;
+}
+
+template <int TM, int WM>
+void go(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM>;
+    constexpr size_t lds = 2 * (6 * 32 * TM * WM + 6 * 64 * (4 / WM)) * 16;
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), lds, stream, p);
+}
+
+}  // namespace
+
+// Scratch (bytes) the bf16x6 weight-gradient path wants for its K-slice partials; -1 = geometry not eligible.
+int64_t rh_wgrad_x6_workspace(const WgradP& w) {
+    Wx6P p;
+    Wx6Plan pl{};
+    if (!plan_wx6(w, &p, &pl)) return -1;
+    return pl.Z > 1 ? (int64_t)pl.Z * w.M * w.C * w.T * (int64_t)sizeof(float) : 0;
+}
+
+// Returns RH_OK with *used = false when the geometry does not fit this path.  ws must hold rh_wgrad_x6_workspace bytes.
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, void* ws, hipStream_t stream, bool* used) {
+    *used = false;
+    Wx6P p;
+    Wx6Plan pl{};
+    if (!plan_wx6(w, &p, &pl)) return RH_OK;
+    p.out = pl.Z > 1 ? (float*)ws : dw;
+    if (pl.wm == 1) {
+        if (pl.tm == 1) go<1, 1>(p, pl, stream);
+        else if (pl.tm == 2) go<2, 1>(p, pl, stream);
+        else go<3, 1>(p, pl, stream);
+    } else {
+        if (pl.tm == 1) go<1, 2>(p, pl, stream);
+        else if (pl.tm == 2) go<2, 2>(p, pl, stream);
+        else go<3, 2>(p, pl, stream);
+    }
+    if (int e = rh_check_launch("conv1d_bwd_weight_x6")) return e;
+    *used = true;
+    if (pl.Z > 1) return rh_reduce_partials_launch((const float*)ws, dw, (long)w.M * w.C * w.T, pl.Z, stream, "conv1d_bwd_weight_reduce");
+    return RH_OK;
+}
