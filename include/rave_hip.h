@@ -180,6 +180,21 @@ int rh_pqmf_synthesis_bwd_f32(const float* dx, const float* w, int32_t rows, int
                               int32_t n_band, int32_t kernel, int32_t pad_left, int32_t n_out,
                               float* dy, rh_stream_t stream);
 
+/* The same four transforms in the FOLDED fast form of the cosine-modulated bank (55.6 MAC/sample instead of 513;
+ * rave/pqmf.py:32-52 get_qmf_bank + :245-294).  `tab` = 384 floats hs[tau] = (-1)^(tau/32) h[tau] (prototype
+ * `pqmf.h`, zero padded) followed by the 16 x 32 matrix Cm[k][m] = 2 cos((2k+1) pi/32 (m - N/2) + (-1)^k pi/4).
+ *   k1 (fold -> matrix):        out[row][k][n] = s(k,n) * scale * sum_m Cm[k][m] sum_j hs[m+32j] in[row][16n + m + 32j + o0]
+ *   k2 (matrix -> overlap-add): out[row][q]    = scale * sum_n' hs[tau] * sum_c Cm[c][tau%32] s(c,n') in[row][c][n'],
+ *                                                tau = q - 16 n' + dp in [0, 384)
+ * with s = reverse_half's sign (-1 iff k odd and n even) and zero extension of `in`.  With lpad = (512 - len(h)) / 2:
+ *   analysis forward   = k1(x,  o0 = lpad - pad_left, scale 1)        analysis backward  = k2(dy, dp = pad_left - lpad, 1)
+ *   synthesis forward  = k2(y,  dp = 496 - 16 pad_left - lpad, 16)    synthesis backward = k1(dx, o0 = lpad - (496 - 16 pad_left), 16)
+ * Valid only while forward_conv / inverse_conv hold the designed bank (the caller checks; they are never trained). */
+int rh_pqmf_fold_k1_f32(const float* in, const float* tab, int32_t rows, int32_t t_len, int32_t n_frames, int32_t o0,
+                        float scale, float* out, rh_stream_t stream);
+int rh_pqmf_fold_k2_f32(const float* in, const float* tab, int32_t rows, int32_t n_frames, int32_t n_out, int32_t dp,
+                        float scale, float* out, rh_stream_t stream);
+
 /* ---- small fused elementwise ops ------------------------------------------------------- */
 
 /* GeneratorV2 output head (rave/blocks.py:705-711): y = tanh(a * sigmoid(m)), with

@@ -77,6 +77,8 @@ def _load() -> C.CDLL:
         "rh_pqmf_analysis_bwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
         "rh_pqmf_synthesis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
         "rh_pqmf_synthesis_bwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
+        "rh_pqmf_fold_k1_f32": ([P, P, I32, I32, I32, I32, F, P, P], C.c_int),
+        "rh_pqmf_fold_k2_f32": ([P, P, I32, I32, I32, I32, F, P, P], C.c_int),
         "rh_amp_tanh_fwd_f32": ([P, I32, I32, I32, P, P], C.c_int),
         "rh_amp_tanh_bwd_f32": ([P, P, I32, I32, I32, P, P], C.c_int),
         "rh_act_fwd_f32": ([P, P, I32, F, I32, I32, I32, P, P], C.c_int),

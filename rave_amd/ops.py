@@ -446,9 +446,11 @@ def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, stride=1, p
 
 
 # --------------------------------------------------------------------------- PQMF
+# ``fold`` = (tab, lpad): the folded fast form (rh_pqmf_fold_k{1,2}_f32) instead of the direct-form MFMA kernels; the
+# caller (rave_amd/pqmf.py) only passes it while the stored bank equals the closed-form cosine-modulated one.
 class _PqmfAnalysisFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, pad: Tuple[int, int]):
+    def forward(ctx, x, w, pad: Tuple[int, int], fold=None):
         x = _chk(x, "x"); w = _chk(w, "forward_conv.weight")
         rows, one, t = x.shape
         if one != 1:
@@ -456,10 +458,16 @@ class _PqmfAnalysisFn(torch.autograd.Function):
         m, _, k = w.shape
         n_frames = (t + pad[0] + pad[1] - k) // m + 1
         y = torch.empty(rows, m, n_frames, device=x.device, dtype=torch.float32)
-        L.check(L.lib.rh_pqmf_analysis_fwd_f32(L.ptr(x), L.ptr(w), rows, t, m, k, pad[0], n_frames, L.ptr(y), L.stream()),
-                "pqmf_analysis_fwd")
+        if fold is not None:
+            tab, lpad = fold
+            L.check(L.lib.rh_pqmf_fold_k1_f32(L.ptr(x), L.ptr(tab), rows, t, n_frames, lpad - pad[0], 1.0, L.ptr(y), L.stream()),
+                    "pqmf_fold_k1")
+        else:
+            L.check(L.lib.rh_pqmf_analysis_fwd_f32(L.ptr(x), L.ptr(w), rows, t, m, k, pad[0], n_frames, L.ptr(y), L.stream()),
+                    "pqmf_analysis_fwd")
         ctx.save_for_backward(w)
         ctx.geo = (rows, t, m, k, pad[0], n_frames)
+        ctx.fold = fold
         return y
 
     @staticmethod
@@ -468,23 +476,34 @@ class _PqmfAnalysisFn(torch.autograd.Function):
         rows, t, m, k, pl, n_frames = ctx.geo
         dy = _chk(dy, "dy")
         dx = torch.empty(rows, 1, t, device=dy.device, dtype=torch.float32)
-        L.check(L.lib.rh_pqmf_analysis_bwd_f32(L.ptr(dy), L.ptr(w), rows, t, m, k, pl, n_frames, L.ptr(dx), L.stream()),
-                "pqmf_analysis_bwd")
-        return dx, None, None
+        if ctx.fold is not None:
+            tab, lpad = ctx.fold
+            L.check(L.lib.rh_pqmf_fold_k2_f32(L.ptr(dy), L.ptr(tab), rows, n_frames, t, pl - lpad, 1.0, L.ptr(dx), L.stream()),
+                    "pqmf_fold_k2")
+        else:
+            L.check(L.lib.rh_pqmf_analysis_bwd_f32(L.ptr(dy), L.ptr(w), rows, t, m, k, pl, n_frames, L.ptr(dx), L.stream()),
+                    "pqmf_analysis_bwd")
+        return dx, None, None, None
 
 
 class _PqmfSynthesisFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, w, pad: Tuple[int, int]):
+    def forward(ctx, y, w, pad: Tuple[int, int], fold=None):
         y = _chk(y, "y"); w = _chk(w, "inverse_conv.weight")
         rows, m, n_frames = y.shape
         k = w.shape[2]
         n_out = n_frames + pad[0] + pad[1] - k + 1
         x = torch.empty(rows, 1, n_out * m, device=y.device, dtype=torch.float32)
-        L.check(L.lib.rh_pqmf_synthesis_fwd_f32(L.ptr(y), L.ptr(w), rows, n_frames, m, k, pad[0], n_out, L.ptr(x), L.stream()),
-                "pqmf_synthesis_fwd")
+        if fold is not None:
+            tab, lpad = fold
+            L.check(L.lib.rh_pqmf_fold_k2_f32(L.ptr(y), L.ptr(tab), rows, n_frames, n_out * m, 496 - 16 * pad[0] - lpad, 16.0,
+                                              L.ptr(x), L.stream()), "pqmf_fold_k2")
+        else:
+            L.check(L.lib.rh_pqmf_synthesis_fwd_f32(L.ptr(y), L.ptr(w), rows, n_frames, m, k, pad[0], n_out, L.ptr(x), L.stream()),
+                    "pqmf_synthesis_fwd")
         ctx.save_for_backward(w)
         ctx.geo = (rows, n_frames, m, k, pad[0], n_out)
+        ctx.fold = fold
         return x
 
     @staticmethod
@@ -493,17 +512,22 @@ class _PqmfSynthesisFn(torch.autograd.Function):
         rows, n_frames, m, k, pl, n_out = ctx.geo
         dx = _chk(dx, "dx")
         dy = torch.empty(rows, m, n_frames, device=dx.device, dtype=torch.float32)
-        L.check(L.lib.rh_pqmf_synthesis_bwd_f32(L.ptr(dx), L.ptr(w), rows, n_frames, m, k, pl, n_out, L.ptr(dy), L.stream()),
-                "pqmf_synthesis_bwd")
-        return dy, None, None
+        if ctx.fold is not None:
+            tab, lpad = ctx.fold
+            L.check(L.lib.rh_pqmf_fold_k1_f32(L.ptr(dx), L.ptr(tab), rows, n_out * m, n_frames, lpad - (496 - 16 * pl), 16.0,
+                                              L.ptr(dy), L.stream()), "pqmf_fold_k1")
+        else:
+            L.check(L.lib.rh_pqmf_synthesis_bwd_f32(L.ptr(dx), L.ptr(w), rows, n_frames, m, k, pl, n_out, L.ptr(dy), L.stream()),
+                    "pqmf_synthesis_bwd")
+        return dy, None, None, None
 
 
-def pqmf_analysis(x: Tensor, w: Tensor, pad: Tuple[int, int]) -> Tensor:
-    return _PqmfAnalysisFn.apply(x, w, pad)
+def pqmf_analysis(x: Tensor, w: Tensor, pad: Tuple[int, int], fold=None) -> Tensor:
+    return _PqmfAnalysisFn.apply(x, w, pad, fold)
 
 
-def pqmf_synthesis(y: Tensor, w: Tensor, pad: Tuple[int, int]) -> Tensor:
-    return _PqmfSynthesisFn.apply(y, w, pad)
+def pqmf_synthesis(y: Tensor, w: Tensor, pad: Tuple[int, int], fold=None) -> Tensor:
+    return _PqmfSynthesisFn.apply(y, w, pad, fold)
 
 
 # --------------------------------------------------------------------------- small ops

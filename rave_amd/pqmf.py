@@ -14,6 +14,7 @@ trajectories of encoder/decoder/discriminator are unaffected.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -39,11 +40,18 @@ def loss_wc(wc, atten, M, N):
     return np.max(g)
 
 
+_PROTOTYPES = {}
+
+
 def get_prototype(atten, M, N=None):
-    """rave/pqmf.py:83-89."""
-    from scipy.optimize import fmin
-    wc = fmin(lambda w: loss_wc(w, atten, M, N), 1 / M, disp=0)[0]
-    return kaiser_filter(wc, atten, N)
+    """rave/pqmf.py:83-89.  The design (about 100 firwin calls inside scipy's fmin, several seconds) is a pure function
+    of its arguments: the result is memoised per process."""
+    key = (float(atten), int(M), None if N is None else int(N))
+    if key not in _PROTOTYPES:
+        from scipy.optimize import fmin
+        wc = fmin(lambda w: loss_wc(w, atten, M, N), 1 / M, disp=0)[0]
+        _PROTOTYPES[key] = kaiser_filter(wc, atten, N)
+    return _PROTOTYPES[key].copy()
 
 
 def get_qmf_bank(h, n_band):
@@ -54,6 +62,55 @@ def get_qmf_bank(h, n_band):
     p = (-1) ** k * math.pi / 4
     mod = torch.cos((2 * k + 1) * math.pi / (2 * n_band) * t + p)
     return 2 * h * mod
+
+
+def fold_tables(h: torch.Tensor, hk: torch.Tensor, tol: float = 5e-6):
+    """Operands of the folded fast form (rave_amd/csrc/pqmf_fold.hip) for a 16-band bank:
+    the signed prototype hs[tau] = (-1)^(tau/32) h[tau] (zero padded to 384) and Cm[k][m] = 2 cos((2k+1) pi/32 (m - N/2)
+    + (-1)^k pi/4), computed in float64 from the module's own ``h`` buffer.  Returns ``(tab, lpad)`` -- or None when the
+    stored bank ``hk`` (what forward_conv / inverse_conv hold) is NOT the closed-form cosine-modulated bank of ``h`` to
+    ``tol`` relative L2 (a checkpoint with edited filters, another band count, a longer prototype): the direct-form
+    kernels, exact w.r.t. the stored taps, are used then."""
+    n = h.numel()
+    if hk.dim() != 2 or hk.shape[0] != 16 or hk.shape[1] != 512 or n > 384 or n % 2 == 0:
+        return None
+    h64 = h.detach().double().cpu()
+    tau = torch.arange(384)
+    hs = torch.zeros(384, dtype=torch.float64)
+    hs[:n] = h64
+    hs = hs * ((-1.0) ** (tau // 32))
+    k = torch.arange(16, dtype=torch.float64).reshape(-1, 1)
+    m = torch.arange(32, dtype=torch.float64).reshape(1, -1)
+    cm = 2 * torch.cos((2 * k + 1) * math.pi / 32 * (m - n // 2) + ((-1.0) ** k) * math.pi / 4)
+    lpad = (512 - n) // 2
+    closed = torch.zeros(16, 512, dtype=torch.float64)
+    closed[:, lpad:lpad + n] = hs[None, :n] * cm[:, tau[:n] % 32]
+    ref = hk.detach().double().cpu()
+    err = float((closed - ref).norm() / ref.norm())
+    if not err < tol:
+        return None
+    return torch.cat([hs, cm.reshape(-1)]).float(), lpad
+
+
+def _fold_enabled() -> bool:
+    return os.environ.get("RH_PQMF_FOLD", "1") != "0"
+
+
+class _FoldMixin:
+    """Lazily builds (and caches per device) the folded-form operands; ``None`` = use the direct-form kernels."""
+
+    def _fold(self, w_fwd: torch.Tensor):
+        if not _fold_enabled() or self.n_band != 16:
+            return None
+        key = (w_fwd.data_ptr(), w_fwd._version, str(w_fwd.device))
+        cache = getattr(self, "_fold_cache", None)
+        if cache is None or cache[0] != key:
+            # the stored conv weight is hk plus the make_odd zero tap: compare the bank it actually holds
+            bank = w_fwd.detach().reshape(w_fwd.shape[0], -1)[:, :512]
+            ft = fold_tables(self.h, bank)
+            cache = (key, None if ft is None else (ft[0].to(w_fwd.device), ft[1]))
+            self._fold_cache = cache
+        return cache[1]
 
 
 def center_pad_next_pow_2(x):
@@ -70,7 +127,7 @@ def make_odd(x):
     return x
 
 
-class CachedPQMF(nn.Module):
+class CachedPQMF(_FoldMixin, nn.Module):
     def __init__(self, attenuation, n_band, polyphase=True, n_channels=1):
         super().__init__()
         if n_band != 16 and n_band != 1:
@@ -105,17 +162,34 @@ class CachedPQMF(nn.Module):
         """(B*C, 1, T) -> (B*C, 16, T/16), reverse_half fused (rave/pqmf.py:279-283)."""
         if self.n_band == 1:
             return x
-        return ops.pqmf_analysis(x, self.forward_conv.weight, self.forward_conv._pad)
+        return ops.pqmf_analysis(x, self.forward_conv.weight, self.forward_conv._pad, self._fold(self.forward_conv.weight))
 
     def inverse(self, x):
         """(B*C, 16, N) -> (B*C, 1, 16 N); sign flip, x16, band reversal, interleave fused
         (rave/pqmf.py:285-294)."""
         if self.n_band == 1:
             return x
-        return ops.pqmf_synthesis(x, self.inverse_conv.weight, self.inverse_conv._pad)
+        # (the synthesis bank is the time-reversed analysis bank: one check of forward_conv covers both; an edited
+        # inverse_conv alone is caught by comparing it with the flipped forward bank)
+        fold = self._fold(self.forward_conv.weight)
+        if fold is not None and not self._inverse_matches():
+            fold = None
+        return ops.pqmf_synthesis(x, self.inverse_conv.weight, self.inverse_conv._pad, fold)
+
+    def _inverse_matches(self) -> bool:
+        w = self.inverse_conv.weight
+        key = (w.data_ptr(), w._version)
+        c = getattr(self, "_inv_ok", None)
+        if c is None or c[0] != key:
+            hk = self.forward_conv.weight.detach().reshape(16, -1)[:, :512]
+            m = hk.shape[0]
+            want = make_odd(hk.flip(-1).reshape(m, -1, m).permute(2, 0, 1))
+            ok = bool(torch.equal(want.to(w.device), w.detach()))
+            c = self._inv_ok = (key, ok)
+        return c[1]
 
 
-class PQMF(nn.Module):
+class PQMF(_FoldMixin, nn.Module):
     """rave/pqmf.py:179-242, the non-cached filterbank (``polyphase_forward/inverse`` :92-134 or
     ``classic_forward/inverse`` :137-176; not bound by any shipped .gin, kept as the cross-check the reference
     itself uses).  state_dict: buffers ``hk``, ``h`` only.  Both analysis variants equal CachedPQMF.forward
@@ -148,7 +222,7 @@ class PQMF(nn.Module):
         if self.n_band == 1:
             return x
         half = self.hk.shape[-1] // 2
-        return ops.pqmf_analysis(x, self._w_fwd, (half, half))
+        return ops.pqmf_analysis(x, self._w_fwd, (half, half), self._fold(self._w_fwd))
 
     def inverse(self, x):
         if x.ndim == 2:
@@ -159,4 +233,4 @@ class PQMF(nn.Module):
         if self.n_band == 1:
             return x
         taps = self._w_inv.shape[-1] - 1          # 32 polyphase taps (+1 zero from make_odd)
-        return ops.pqmf_synthesis(x, self._w_inv, (taps // 2 - 1, taps // 2 + 1))
+        return ops.pqmf_synthesis(x, self._w_inv, (taps // 2 - 1, taps // 2 + 1), self._fold(self._w_fwd))

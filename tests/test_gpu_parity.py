@@ -1272,3 +1272,63 @@ def test_graphed_training_step_is_bit_identical_to_eager(dev):
     assert moved > 50                      # the optimizer really ran
     for k in ("fullband_spectral_distance", "multiband_spectral_distance", "regularization"):
         assert torch.equal(le[k].detach(), lg[k].detach()), k
+
+
+# --------------------------------------------------------------------------- PQMF, folded fast form
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("t_len", [16, 48, 4096 + 16, 65536])
+def test_pqmf_folded_form_vs_direct_form_and_oracle(dev, t_len, causal):
+    """rave_amd/csrc/pqmf_fold.hip (55.6 MAC/sample, HBM-bound) vs the direct-form MFMA kernels (exact w.r.t. the
+    stored taps) and the CPU oracle: analysis / synthesis and both input gradients, centred and causal pads, ragged
+    lengths.  The two forms differ by the fp32 rounding of the stored bank (SURVEY.md Appendix B #15: ~5e-6)."""
+    import os
+    from rave_amd import cc, pqmf
+    cc.set_default_padding_mode("causal" if causal else "centered")
+    try:
+        m = pqmf.CachedPQMF(100, 16).to(dev)
+    finally:
+        cc.set_default_padding_mode("centered")
+    rows = 3 if t_len < 65536 else 2
+    x = O.synthetic_batch(rows, 1, t_len, seed=t_len + 1)
+    gen = torch.Generator().manual_seed(t_len)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["RH_PQMF_FOLD"] = mode
+        try:
+            xa = x.to(dev).requires_grad_(True)
+            y = m(xa)
+            cy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            (y * cy).sum().backward()
+            ya = y.detach().clone().requires_grad_(True)
+            xr = m.inverse(ya)
+            cx = torch.randn(xr.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            (xr * cx).sum().backward()
+            outs[mode] = (y.detach(), xa.grad, xr.detach(), ya.grad)
+        finally:
+            os.environ.pop("RH_PQMF_FOLD", None)
+    assert m._fold(m.forward_conv.weight) is not None            # the designed bank passes the closed-form gate
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a.shape == b.shape
+        assert rel_l2(a, b) < 1e-5
+    # sign / band indexing: identical wherever the coefficient is not negligible
+    big = outs["0"][0].abs() > 1e-4
+    assert torch.equal(torch.sign(outs["1"][0])[big], torch.sign(outs["0"][0])[big])
+    sd = O.pqmf_buffers(100, 16)
+    y_ref = O.pqmf_analysis(x, sd["forward_conv.weight"], causal)
+    assert rel_l2(outs["1"][0], y_ref) < TOL_OP
+    assert rel_l2(outs["1"][2], O.pqmf_synthesis(outs["1"][0].cpu(), sd["inverse_conv.weight"], causal)) < TOL_OP
+
+
+def test_pqmf_folded_form_is_gated_on_the_stored_bank(dev):
+    """An edited filter bank (anything but the closed-form cosine-modulated one) must take the direct-form kernels,
+    which are exact w.r.t. the stored taps."""
+    from rave_amd import ops as R, pqmf
+    m = pqmf.CachedPQMF(100, 16).to(dev)
+    x = O.synthetic_batch(2, 1, 8192, seed=3).to(dev)
+    with torch.no_grad():
+        m.forward_conv.weight[3, 0, 200] += 1e-2
+    assert m._fold(m.forward_conv.weight) is None
+    y = m(x)
+    assert torch.equal(y, R.pqmf_analysis(x, m.forward_conv.weight, m.forward_conv._pad))
+    ref = O.pqmf_analysis(x.cpu(), m.forward_conv.weight.detach().cpu())
+    assert rel_l2(y, ref) < TOL_OP
