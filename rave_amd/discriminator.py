@@ -18,10 +18,21 @@ from .ops import ACT_LEAKY, ACT_NONE
 
 
 def _map_conv(conv):
-    """gin binds ``conv = @torch.nn.Conv1d`` / ``@nn.Conv2d`` (v1.gin:82-84, v2.gin:53-56)."""
-    if conv in (nn.Conv1d, cc.PlainConv1d):
+    """gin binds ``conv = @torch.nn.Conv1d`` / ``@nn.Conv2d`` (v1.gin:82-84, v2.gin:53-56).  What arrives is the class
+    itself (plain Python), a gin-made subclass of it, or a configurable reference wrapping it -- all are mapped to the
+    HIP operator classes (same constructor signature, same ``weight`` / ``bias`` parameter names)."""
+    base = conv
+    for attr in ("__gin_target__", "__wrapped__", "wrapped"):
+        base = getattr(base, attr, base)
+    if isinstance(base, type):
+        if issubclass(base, (nn.Conv1d, cc.PlainConv1d)):
+            return cc.PlainConv1d
+        if issubclass(base, (nn.Conv2d, cc.Conv2dK1)):
+            return cc.Conv2dK1
+    name = getattr(base, "__name__", "") or getattr(base, "__qualname__", "")
+    if name.endswith("Conv1d"):
         return cc.PlainConv1d
-    if conv in (nn.Conv2d, cc.Conv2dK1):
+    if name.endswith("Conv2d"):
         return cc.Conv2dK1
     raise NotImplementedError(f"rave_amd ConvNet: conv class {conv}")
 

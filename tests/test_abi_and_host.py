@@ -249,3 +249,54 @@ def test_valid_signal_crop_and_lr_schedule_match_reference():
         gen_opt.step()
         m.on_train_batch_end(None, None, 0)
     assert abs(gen_opt.param_groups[0]["lr"] - 1e-4) < 1e-12
+
+
+_GIN_SCRIPT = r'''
+import json, os, sys
+root, overlay = sys.argv[1], sys.argv[2] == "1"
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
+sys.dont_write_bytecode = True
+from ref_import import import_reference
+rave = import_reference()
+import gin, torch
+gin.clear_config()
+files = ["configs/v2.gin"] + ([os.path.join(root, "rave_amd", "configs", "mi355x.gin")] if overlay else [])
+gin.parse_config_files_and_bindings(files, ["CAPACITY = 8", "LATENT_SIZE = 16"])
+torch.manual_seed(0)
+model = rave.RAVE()                       # the reference's own class, every argument from the parsed .gin files
+mods = {k: type(getattr(model, k)).__module__ for k in ("pqmf", "encoder", "decoder", "discriminator")}
+inner = sorted({type(m).__module__.split(".")[0] for m in model.modules()
+                if type(m).__name__ in ("Conv1d", "ConvTranspose1d", "Conv2dK1", "PlainConv1d", "Conv2d")})
+sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+print("RESULT" + json.dumps(dict(mods=mods, conv_roots=inner, sd=sd, skipped=gin.SKIPPED, cls=type(model).__module__,
+                                 crop=bool(model.valid_signal_crop), every=model.update_discriminator_every)))
+'''
+
+
+def test_gin_overlay_builds_the_unmodified_rave_on_the_drop_in_modules():
+    """rave_amd/configs/mi355x.gin, parsed AFTER the reference's own configs/v2.gin (which includes v1.gin) by the gin
+    shim, makes the UNMODIFIED ``rave.model.RAVE`` construct its pqmf / encoder / decoder / discriminator from the
+    HIP drop-in classes -- with exactly the state_dict keys and shapes the stock configuration produces.
+    (Construction only: no GPU here, and /root/reference does not exist on the GPU box.)"""
+    import json, os, subprocess, sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference/rave"):
+        pytest.skip("reference tree not present (GPU box)")
+
+    def run(overlay):
+        r = subprocess.run([sys.executable, "-c", _GIN_SCRIPT, root, "1" if overlay else "0"], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+
+    ref, hip = run(False), run(True)
+    assert ref["cls"] == hip["cls"] == "rave.model"                    # the reference's own RAVE in both builds
+    assert set(ref["mods"].values()) <= {"rave.pqmf", "rave.blocks", "rave.discriminator"}
+    assert hip["mods"] == {"pqmf": "rave_amd.pqmf", "encoder": "rave_amd.blocks", "decoder": "rave_amd.blocks",
+                           "discriminator": "rave_amd.discriminator"}
+    assert hip["conv_roots"] == ["rave_amd"]                           # no torch / cached_conv convolution left
+    assert hip["crop"] and hip["every"] == 4                           # v2.gin's own rave.RAVE bindings still apply
+    drop = lambda sd: {k: v for k, v in sd.items() if not k.endswith(("paddings.0.pad", ".pad"))}
+    assert drop(hip["sd"]) == drop(ref["sd"])
+    assert all(s.startswith("dataset.") for s in hip["skipped"])       # only rave.dataset (udls / lmdb) is out of reach
