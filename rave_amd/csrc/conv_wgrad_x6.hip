@@ -7,10 +7,12 @@
 // GEMM view: rows m, columns (c, t), reduction over POSITIONS -- the contiguous axis of both operands.  A 16-deep MFMA
 // k block is 16 consecutive positions of one batch item, and lane (j, g)'s fragment is 8 consecutive samples of one
 // row: no transposition anywhere, every thread converts whole fragments.  Per step (16 positions):
-//   * every thread owns (row, half) tasks of the R tile and (column, half) tasks of the S tile: it loads the 8 samples
-//     straight from HBM/L2 one step ahead (buffer loads: padding and ragged tails read 0.0), applies LeakyReLU, splits
-//     exactly and writes three 16-byte fragments [g][piece][row] to the other LDS stage;
-//   * wave tile 32*TM x 64, fragments by ds_read_b128, 12*TM MFMAs per step and wave, one barrier per step.
+//   * every thread owns (row, octet) tasks of the R tile and (column, octet) tasks of the S tile: it loads the 8 samples
+//     straight from HBM/L2 one step ahead (buffer loads: padding and ragged tails read 0.0; consecutive lanes take
+//     consecutive octets of one row, i.e. whole 128-byte lines), applies LeakyReLU, splits exactly and writes three
+//     16-byte fragments [k block][g][piece][row] to LDS;
+//   * a step is two k blocks (32 positions): wave tile 32*TM x 64, fragments by ds_read_b128, 24*TM MFMAs per step and
+//     wave; one LDS stage (the next step's samples wait in registers), two barriers per step.
 // Both operands need the conversion (the forward kernel gets its weights pre-split), ~4 VALU instructions per MFMA, so
 // this kernel lives off the overlap of one workgroup's conversion with the other's MFMAs (2 workgroups per CU).
 // K is split over (batch, position) ranges; the partial sums are combined in slice order by reduce_partials_kernel.
@@ -31,7 +33,7 @@ struct Wx6P {
     int B, M, C, T, N;          // N = C * T
     int r_row, s_row, s_valid, is;
     float r_slope, s_slope;     // LeakyReLU slope of the operand's activation; 1 = none
-    int steps_per_b;            // ceil(r_row / 16)
+    int steps_per_b;            // ceil(r_row / (16 * kKS))
     int total_steps, steps_per_z;
     unsigned r_bytes, s_bytes;
     int minoff, maxoff;
@@ -63,15 +65,18 @@ __device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* ds
     }
 }
 
+constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
+
 template <int TM, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 64 * WN;
-    constexpr int A_UNITS = 6 * BM, B_UNITS = 6 * BN;
-    constexpr int NA = (2 * BM + 255) / 256, NB = (2 * BN + 255) / 256;      // tasks per thread and step
+    constexpr int A_UNITS = 6 * BM, B_UNITS = 6 * BN;                     // fragments of ONE k block
+    constexpr int OCT = 2 * kKS;                                          // 8-sample octets per row and step
+    constexpr int NA = (OCT * BM + 255) / 256, NB = (OCT * BN + 255) / 256;   // tasks per thread and step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4* const a_st = reinterpret_cast<u32x4*>(smem_raw);
-    u32x4* const b_st = a_st + 2 * A_UNITS;
+    u32x4* const a_st = reinterpret_cast<u32x4*>(smem_raw);              // [kKS][g][piece][BM]
+    u32x4* const b_st = a_st + kKS * A_UNITS;                             // [kKS][g][piece][BN]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,26 +87,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
     const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.S), 0, p.s_bytes, 0x00020000);
 
-    // ---- tasks (chunk-invariant): row part of the element offset, fragment slot in the stage, tap offset
+    // ---- tasks (step-invariant).  A task = 8 consecutive samples of one row; consecutive lanes take consecutive
+    // octets of the SAME row (OCT lanes x 32 bytes = one 128-byte line per row), so that a load instruction touches
+    // 64 / OCT rows instead of 64.
     unsigned aoff[NA], boff[NB];
-    int adst[NA], bdst[NB], ag8[NA], bp0[NB];
+    int adst[NA], bdst[NB], apos[NA], bp0[NB];
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
         const int u = tid + 256 * q;
-        const int gg = u / BM, m = u - gg * BM;
-        const bool ok = u < 2 * BM && m0 + m < p.M;
-        adst[q] = u < 2 * BM ? gg * 3 * BM + m : -1;
-        ag8[q] = 8 * gg;
-        aoff[q] = ok ? (unsigned)(((m0 + m) * p.r_row + 8 * gg) * 4) : kOOB;
+        const int o = u % OCT, m = u / OCT;
+        const bool ok = m < BM && m0 + m < p.M;
+        adst[q] = m < BM ? (o >> 1) * A_UNITS + (o & 1) * 3 * BM + m : -1;
+        apos[q] = 8 * o;
+        aoff[q] = ok ? (unsigned)(((m0 + m) * p.r_row + 8 * o) * 4) : kOOB;
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int u = tid + 256 * q;
-        const int gg = u / BN, col = u - gg * BN;
+        const int o = u % OCT, col = u / OCT;
         const int cc = (n0 + col) / p.T, t = (n0 + col) - cc * p.T;
-        const bool ok = u < 2 * BN && n0 + col < p.N;
-        bdst[q] = u < 2 * BN ? gg * 3 * BN + col : -1;
-        bp0[q] = 8 * gg * p.is + (ok ? p.off[t] : 0);                 // position of sample 0 relative to n * is
+        const bool ok = col < BN && n0 + col < p.N;
+        bdst[q] = col < BN ? (o >> 1) * B_UNITS + (o & 1) * 3 * BN + col : -1;
+        bp0[q] = 8 * o * p.is + (ok ? p.off[t] : 0);                  // position of sample 0 relative to n * is
         boff[q] = ok ? (unsigned)((cc * p.s_row + bp0[q]) * 4) : kOOB;
     }
 
@@ -113,14 +120,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+    constexpr int SPAN = 16 * kKS;                                        // positions per step
     float ra[NA][8], rb[NB][8];
     auto load = [&](int st) {
         const int b = st / p.steps_per_b;
-        const int n = (st - b * p.steps_per_b) * 16;
+        const int n = (st - b * p.steps_per_b) * SPAN;
         const unsigned rs = (unsigned)((b * p.M * p.r_row + n) * 4);
         const unsigned ss = (unsigned)((b * p.C * p.s_row + n * p.is) * 4);
-        const bool r_tail = n + 16 > p.r_row;                                      // uniform
-        const bool s_edge = n * p.is + p.minoff < 0 || (n + 15) * p.is + p.maxoff >= p.s_valid || r_tail;
+        const bool r_tail = n + SPAN > p.r_row;                                     // uniform
+        const bool s_edge = n * p.is + p.minoff < 0 || (n + SPAN - 1) * p.is + p.maxoff >= p.s_valid || r_tail;
         // the whole element offset goes into the per-lane operand (the bounds check must see it: a tap offset alone
         // can be negative for a valid sample), nothing into the scalar offset
 #pragma unroll
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 unsigned off = base == kOOB ? kOOB : base + 4u * i;
-                if (r_tail) off = n + ag8[q] + i < p.r_row ? off : kOOB;
+                if (r_tail) off = n + apos[q] + i < p.r_row ? off : kOOB;
                 ra[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
             }
         }
@@ -147,47 +155,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
             }
         }
     };
-    auto convert = [&](int stage) {
+    auto convert = [&]() {
 #pragma unroll
         for (int q = 0; q < NA; ++q)
-            if (adst[q] >= 0) emit(ra[q], p.r_slope, a_st + stage * A_UNITS + adst[q], BM);
+            if (adst[q] >= 0) emit(ra[q], p.r_slope, a_st + adst[q], BM);
 #pragma unroll
         for (int q = 0; q < NB; ++q)
-            if (bdst[q] >= 0) emit(rb[q], p.s_slope, b_st + stage * B_UNITS + bdst[q], BN);
+            if (bdst[q] >= 0) emit(rb[q], p.s_slope, b_st + bdst[q], BN);
     };
 
     const int st0 = z * p.steps_per_z;
     const int nst = min(p.steps_per_z, p.total_steps - st0);
     if (nst > 0) {
         load(st0);
-        convert(0);
+        convert();
     }
     __syncthreads();
     const int arow = g * 3 * BM + wm * TM * 32 + j;
     const int bcol = g * 3 * BN + wn * 64 + j;
+    // one LDS stage: the next step's samples wait in registers while the matrix cores work on this step's fragments
+    // (the other workgroup of the CU runs its MFMAs while this one converts)
     for (int s = 0; s < nst; ++s) {
         const bool more = s + 1 < nst;
         if (more) load(st0 + s + 1);
-        const u32x4* al = a_st + (s & 1) * A_UNITS + arow;
-        const u32x4* bl = b_st + (s & 1) * B_UNITS + bcol;
-        bf16x8 bfr[2][3], afr[TM][3];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int kb = 0; kb < kKS; ++kb) {
+            const u32x4* al = a_st + kb * A_UNITS + arow;
+            const u32x4* bl = b_st + kb * B_UNITS + bcol;
+            bf16x8 bfr[2][3], afr[TM][3];
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
+            for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
-        constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
+                for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn], 0, 0, 0);
-        if (more) convert((s + 1) & 1);
+                for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+            constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();                 // every wave is done reading this step's fragments
+        if (more) convert();
         __syncthreads();
     }
 
@@ -234,7 +248,7 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     p->r_row = w.r_row; p->s_row = w.s_row; p->s_valid = w.s_valid; p->is = w.is;
     p->r_slope = w.r_act == RH_ACT_LEAKY ? w.r_slope : 1.f;
     p->s_slope = w.s_act == RH_ACT_LEAKY ? w.s_slope : 1.f;
-    p->steps_per_b = rh_cdiv(w.r_row, 16);
+    p->steps_per_b = rh_cdiv(w.r_row, 16 * kKS);
     p->total_steps = w.B * p->steps_per_b;
     p->r_bytes = (unsigned)rb; p->s_bytes = (unsigned)sb;
     p->minoff = w.minoff; p->maxoff = w.maxoff;
@@ -247,7 +261,7 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     pl->ct = rh_cdiv(p->N, BN);
     static const int target = [] { const char* e2 = getenv("RH_WGRAD_X6_BLOCKS"); return e2 ? atoi(e2) : 1024; }();
     int Z = rh_cdiv(target, pl->rt * pl->ct);
-    const int zmax = p->total_steps / 8 > 0 ? p->total_steps / 8 : 1;     // at least 8 steps (128 positions) per slice
+    const int zmax = p->total_steps / 4 > 0 ? p->total_steps / 4 : 1;     // at least 4 steps (128 positions) per slice
     if (Z > zmax) Z = zmax;
     if (Z < 1) Z = 1;
     pl->steps_per_z = rh_cdiv(p->total_steps, Z);
@@ -259,7 +273,7 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
 template <int TM, int WM>
 void go(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
     auto kern = wgrad_x6_kernel<TM, WM, 4 / WM>;
-    constexpr size_t lds = 2 * (6 * 32 * TM * WM + 6 * 64 * (4 / WM)) * 16;
+    constexpr size_t lds = kKS * (6 * 32 * TM * WM + 6 * 64 * (4 / WM)) * 16;
     static std::once_flag once;
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
