@@ -282,11 +282,11 @@ def main():
         # every launch is priced against the peak of the instruction it issues: conv_x6_kernel = exact f32 as six
         # v_mfma_f32_32x32x16_bf16 per product block (2.5 PF / 6 = 417 TFLOP/s f32-equivalent); the f32-input MFMA
         # kernels (conv_igemm_dma_kernel forward / data gradient of the few geometries x6 does not take, and
-        # wgrad_dma_kernel) = 157.3 TFLOP/s
+        # wgrad_dma_kernel for the <= 96-row weight gradients on long sequences) = 157.3 TFLOP/s
         peak_of = lambda k: X6_MFMA_PEAK if k.endswith("[x6]") else F32_MFMA_PEAK
         kern_of = {"conv_fwd[x6]": "conv_x6_kernel", "conv_dgrad[x6]": "conv_x6_kernel",
                    "conv_fwd[f32]": "conv_igemm_dma_kernel", "conv_dgrad[f32]": "conv_igemm_dma_kernel",
-                   "conv_wgrad": "wgrad_dma_kernel"}
+                   "conv_wgrad[f32]": "wgrad_dma_kernel", "conv_wgrad[x6]": "wgrad_x6_kernel"}
         byk = {}
         for k, v in agg.items():
             a = byk.setdefault(kern_of.get(k, k), [0, 0.0, 0.0, 0.0, peak_of(k)])
@@ -295,8 +295,8 @@ def main():
         dom_name = max(byk, key=lambda k: byk[k][3])
         n, fl, by, ms, peak = byk[dom_name]
         out["roofline"] = {
-            "bound": "mfma", "kernel": dom_name + (" (forward + data-gradient launches)" if dom_name != "wgrad_dma_kernel"
-                                                   else " (weight-gradient launches)"),
+            "bound": "mfma", "kernel": dom_name + (" (weight-gradient launches)" if dom_name.startswith("wgrad")
+                                                   else " (forward + data-gradient launches)"),
             "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": fl / (ms * 1e-3) / peak, "frac_vs_exact_f32_peak": fl / (ms * 1e-3) / F32_MFMA_PEAK,
             "traffic": None,

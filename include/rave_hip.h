@@ -142,6 +142,8 @@ int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d);
  * kernels, < 0 = invalid descriptor.  Measurement only (bench.py prices every launch against the peak of the
  * instruction it issues); has_bias / has_add = the optional operands are non-NULL. */
 int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add);
+/* Same question for rh_conv1d_bwd_weight_f32: 1 = wgrad_x6_kernel (bf16 matrix cores), 0 = f32-input MFMA kernels. */
+int rh_conv1d_bwd_weight_kernel_family(const rh_conv1d_desc* d);
 
 /* dx = act'(x) * conv_bwd_data(dy) + add.   `x` is the forward input (needed when act != NONE),
  * `add` (B,c_in,l_in*inner) may be NULL (residual-branch gradient). */

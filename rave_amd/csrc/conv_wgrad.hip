@@ -573,6 +573,15 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
 int64_t rh_wgrad_x6_workspace(const WgradP& w);
 int rh_wgrad_x6_launch(const WgradP& w, float* dw, void* ws, hipStream_t stream, bool* used);
 
+extern "C" int rh_conv1d_bwd_weight_kernel_family(const rh_conv1d_desc* d) {
+    if (!d || d->batch <= 0) return 0;
+    WgradP p{};
+    fill(d, &p);
+    alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+    p.R = dummy; p.S = dummy;
+    return d->act != RH_ACT_SNAKE && rh_wgrad_x6_workspace(p) >= 0 ? 1 : 0;
+}
+
 int64_t rh_wgrad_workspace(const rh_conv1d_desc* d) {
     WgradP p{};
     fill(d, &p);

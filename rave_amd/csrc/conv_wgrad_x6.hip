@@ -67,7 +67,8 @@ __device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* ds
 
 constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
 
-template <int TM, int WM, int WN>
+// AV: rows of R are 16-byte aligned -> the 8 samples of an R task are two 16-byte loads instead of eight 4-byte ones
+template <int TM, int WM, int WN, bool AV>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 64 * WN;
@@ -134,11 +135,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const unsigned base = aoff[q] == kOOB ? kOOB : aoff[q] + rs;
+            if constexpr (AV) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                unsigned off = base == kOOB ? kOOB : base + 4u * i;
-                if (r_tail) off = n + apos[q] + i < p.r_row ? off : kOOB;
-                ra[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
+                for (int h = 0; h < 2; ++h) {
+                    unsigned off = base == kOOB ? kOOB : base + 16u * h;
+                    if (r_tail) off = n + apos[q] + 4 * h < p.r_row ? off : kOOB;      // r_row % 4 == 0: all or nothing
+                    const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[q][4 * h + i] = __uint_as_float(v[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned off = base == kOOB ? kOOB : base + 4u * i;
+                    if (r_tail) off = n + apos[q] + i < p.r_row ? off : kOOB;
+                    ra[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, off, 0, 0));
+                }
             }
         }
 #pragma unroll
@@ -233,12 +245,12 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     if (w.inner != 1 || w.T > kMaxTaps || w.B <= 0 || w.r_row <= 0) return false;
     if ((w.r_act != RH_ACT_NONE && w.r_act != RH_ACT_LEAKY) || (w.s_act != RH_ACT_NONE && w.s_act != RH_ACT_LEAKY)) return false;
     if (w.M < 32 || (long)w.C * w.T < 64) return false;            // tiny GEMMs (first discriminator layers): f32 kernels
-    // Measured per layer (profiles/round2_layer_table_b32.txt): with one fragment = 8 samples of ONE row per lane, a
-    // wave's load instruction touches 64 different rows; that only pays when rows are short (the deep stages: 32 / 64
-    // positions, many channels -- 1.2x ... 2.1x over the f32-MFMA kernel there).  On long rows the LDS-DMA row segments
-    // of wgrad_dma_kernel are the better data path, and pointwise convs have too few columns per converted row.
+    // Measured per layer (profiles/round2_layer_table_b32.txt): 1.2x ... 1.6x over the f32-MFMA kernel (wgrad_dma_kernel)
+    // wherever the weight tensor offers a few output tiles -- everything but the <= 96-row layers on long sequences
+    // (C = 96 at 4096 positions: one to three tiles, so K is cut into hundreds of slices whose partial tiles cost more
+    // than the matrix work; the f32 kernel's 96-column tiles and LDS-DMA row segments win there).
     static const int force = [] { const char* e2 = getenv("RH_WGRAD_X6_ALL"); return e2 ? atoi(e2) : 0; }();
-    if (!force && (w.r_row > 64 || w.T < 3)) return false;
+    if (!force && w.M <= 96 && w.r_row > 1024) return false;
     const unsigned long long rb = 4ull * w.B * w.M * (unsigned long long)w.r_row;
     const unsigned long long sb = 4ull * w.B * w.C * (unsigned long long)w.s_row;
     if (rb >= 0x7fffffffull || sb >= 0x7fffffffull) return false;
@@ -270,15 +282,21 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     return true;
 }
 
-template <int TM, int WM>
-void go(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
-    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM>;
+template <int TM, int WM, bool AV>
+void go2(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM, AV>;
     constexpr size_t lds = kKS * (6 * 32 * TM * WM + 6 * 64 * (4 / WM)) * 16;
     static std::once_flag once;
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     hipLaunchKernelGGL(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), lds, stream, p);
+}
+
+template <int TM, int WM>
+void go(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    if (p.r_row % 4 == 0 && ((uintptr_t)p.R & 15) == 0) go2<TM, WM, true>(p, pl, stream);
+    else go2<TM, WM, false>(p, pl, stream);
 }
 
 }  // namespace

@@ -351,6 +351,9 @@ class GraphedTrainingStep:
                 _restore_opt(o, st)
             for o in m.optimizers():
                 o.zero_grad(set_to_none=True)
+            for mod in m.modules():          # host-side caches keyed on parameter versions (the restore bumped them)
+                if hasattr(mod, "refresh_host_caches"):
+                    mod.refresh_host_caches()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True)

@@ -51,6 +51,8 @@ def _launch(kind: str, d, fn, has_bias=False, has_add=False):
     if kind in ("conv_fwd", "conv_dgrad"):   # which instruction does this launch issue?
         fam = L.lib.rh_conv1d_kernel_family(C.byref(d), 0 if kind == "conv_fwd" else 1, int(has_bias), int(has_add))
         kind += "[x6]" if fam == 1 else "[f32]"
+    elif kind == "conv_wgrad":
+        kind += "[x6]" if L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(d)) == 1 else "[f32]"
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -104,6 +104,8 @@ class _FoldMixin:
             return None
         key = (w_fwd.data_ptr(), w_fwd._version, str(w_fwd.device))
         cache = getattr(self, "_fold_cache", None)
+        if cache is not None and w_fwd.is_cuda and torch.cuda.is_current_stream_capturing():
+            return cache[1]        # a hipGraph is being recorded: no host round trip (refresh_host_caches ran before)
         if cache is None or cache[0] != key:
             # the stored conv weight is hk plus the make_odd zero tap: compare the bank it actually holds
             bank = w_fwd.detach().reshape(w_fwd.shape[0], -1)[:, :512]
@@ -176,10 +178,18 @@ class CachedPQMF(_FoldMixin, nn.Module):
             fold = None
         return ops.pqmf_synthesis(x, self.inverse_conv.weight, self.inverse_conv._pad, fold)
 
+    def refresh_host_caches(self) -> None:
+        """Re-validate the host-side decisions that depend on parameter VALUES (is the stored bank the closed-form
+        one?) -- called before a hipGraph capture, during which no device-to-host copy is possible."""
+        if self.n_band == 16 and self._fold(self.forward_conv.weight) is not None:
+            self._inverse_matches()
+
     def _inverse_matches(self) -> bool:
         w = self.inverse_conv.weight
         key = (w.data_ptr(), w._version)
         c = getattr(self, "_inv_ok", None)
+        if c is not None and w.is_cuda and torch.cuda.is_current_stream_capturing():
+            return c[1]
         if c is None or c[0] != key:
             hk = self.forward_conv.weight.detach().reshape(16, -1)[:, :512]
             m = hk.shape[0]
