@@ -271,7 +271,11 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     const int BM = 32 * pl->tm * pl->wm, BN = 64 * (4 / pl->wm);
     pl->rt = rh_cdiv(w.M, BM);
     pl->ct = rh_cdiv(p->N, BN);
-    static const int target = [] { const char* e2 = getenv("RH_WGRAD_X6_BLOCKS"); return e2 ? atoi(e2) : 1024; }();
+    // K slices: two rounds of workgroups (1024) when the weight tensor has many tiles (the second round's matrix work
+    // covers the first round's partial-tile stores), one round (512) when it has few -- every extra slice is another
+    // copy of the whole weight tensor written and re-read (measured per layer, profiles/round2_layer_table_b32.txt)
+    static const int target_env = [] { const char* e2 = getenv("RH_WGRAD_X6_BLOCKS"); return e2 ? atoi(e2) : 0; }();
+    const int target = target_env > 0 ? target_env : (pl->rt * pl->ct >= 32 ? 1024 : 512);
     int Z = rh_cdiv(target, pl->rt * pl->ct);
     const int zmax = p->total_steps / 4 > 0 ? p->total_steps / 4 : 1;     // at least 4 steps (128 positions) per slice
     if (Z > zmax) Z = zmax;
