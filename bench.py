@@ -195,7 +195,9 @@ def main():
         m.encoder.enabled.fill_(1)
     ddp.broadcast_module(m)
     use_ddp = world > 1 or force_dist
-    use_graph = not args.no_graph and not use_ddp
+    # (the discrete config initialises its RVQ codebooks with k-means inside its first training steps: host-driven,
+    # data-dependent work that a recorded graph cannot contain -- it runs the eager step)
+    use_graph = not args.no_graph and not use_ddp and args.config != "discrete"
     gen_opt, dis_opt = m.configure_optimizers(capturable=use_graph)
     m.warmed_up = args.phase == "gan"
     m.skip_dead_grads = bool(args.skip_dead_grads)

@@ -72,6 +72,17 @@ def _set_warmed_up(mod, state: bool) -> None:
         mod.warmed_up.fill_(int(state))
 
 
+def host_flag(mod, name: str) -> bool:
+    """Truth value of a flag BUFFER (``DiscreteEncoder.enabled``, ``EuclideanCodebook.inited``: tensors in the reference,
+    tested with ``if tensor:`` = a device-to-host sync per forward).  Read from the device as the reference does, except
+    while a hipGraph is being recorded, where the value seen by the preceding eager iterations is used."""
+    buf = getattr(mod, name)
+    cache = mod.__dict__.setdefault("_host_flags", {})
+    if not (buf.is_cuda and torch.cuda.is_current_stream_capturing()) or name not in cache:
+        cache[name] = bool(buf)
+    return cache[name]
+
+
 def _is_warmed_up(mod) -> bool:
     h = getattr(mod, "_warmed_up_host", None)
     if h is None:          # never set through set_warmed_up (e.g. right after load_state_dict): read the buffer once
@@ -487,7 +498,7 @@ class DiscreteEncoder(nn.Module):
         """``eps`` / ``noise``: inject the noise-augmentation draw (parity runs); the step passes it as ``eps``."""
         if noise is None:
             noise = eps
-        if self.enabled:
+        if host_flag(self, "enabled"):
             if self.rvq is None:
                 raise RuntimeError("rave_amd DiscreteEncoder: enabled but constructed without vq_cls")
             z, diff, _ = self.rvq(z)

@@ -92,7 +92,8 @@ class EuclideanCodebook(nn.Module):
 
     def step(self, x2d: torch.Tensor, residual, qsum, want_loss: bool):
         """One fused codebook step on (N, D) vectors; returns (indices, loss partials)."""
-        if not self.inited:
+        from .blocks import host_flag
+        if not host_flag(self, "inited"):
             self.init_embed_(x2d)
         ind, parts = _assign(x2d, self.embed, residual, qsum, want_loss)
         return ind, parts

@@ -1,20 +1,32 @@
-# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/
+# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/r2/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 400 python bench.py --steps 20 --warmup 5 < /dev/null > gpurun_out/bench_final.log 2>&1
-timeout 300 python bench.py --phase gan --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > gpurun_out/bench_gan.log 2>&1
-timeout 300 python bench.py --config discrete --phase gan --batch 32 --steps 4 --warmup 4 < /dev/null > gpurun_out/bench_discrete.log 2>&1
-timeout 300 python bench.py --config v3 --phase gan --batch 16 --steps 4 --warmup 4 < /dev/null > gpurun_out/bench_v3.log 2>&1
-timeout 300 python tools/bench_layers.py < /dev/null > gpurun_out/layers.log 2>&1
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_final -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/prof_final.log 2>&1 < /dev/null)
-f=$(find gpurun_out/prof_final -name "*.db" | head -1)
-[ -n "$f" ] && python tools/prof_summary.py $f > gpurun_out/kernel_stats_final.md 2>&1
-rm -rf gpurun_out/prof_final
-tail -c 600 gpurun_out/bench_final.log; echo; tail -c 300 gpurun_out/bench_gan.log; echo; tail -c 300 gpurun_out/bench_discrete.log; echo; tail -c 300 gpurun_out/bench_v3.log; echo; tail -2 gpurun_out/layers.log; head -12 gpurun_out/kernel_stats_final.md
-# opt-in mode and the data-parallel path exercised with one rank (RCCL init, buckets, hooks)
-timeout 300 python bench.py --phase gan --skip-dead-grads --steps 8 --warmup 4 --no-cpu-baseline --no-kernel-timing < /dev/null > gpurun_out/bench_gan_skip.log 2>&1
-RAVE_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing < /dev/null > gpurun_out/bench_dist1.log 2>&1
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing < /dev/null > gpurun_out/bench_torchrun1.log 2>&1
-for w in v2 encodec descript; do N=32; [ $w = v2 ] && N=64; WHICH=$w N=$N timeout 300 python tools/bench_disc2d.py < /dev/null > gpurun_out/disc_$w.log 2>&1; done
-tail -c 400 gpurun_out/bench_gan_skip.log; echo; tail -c 500 gpurun_out/bench_dist1.log; echo; tail -c 300 gpurun_out/bench_torchrun1.log; echo
-grep "TOTAL\|fwd+bwd" gpurun_out/disc_v2.log gpurun_out/disc_encodec.log gpurun_out/disc_descript.log
+O=gpurun_out/r2; mkdir -p $O
+timeout 400 python bench.py --steps 20 --warmup 5 < /dev/null > $O/bench_n1.log 2>&1
+timeout 200 python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_n1_eager.log 2>&1
+timeout 300 python bench.py --phase gan --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_gan.log 2>&1
+timeout 300 python bench.py --phase gan --skip-dead-grads --steps 8 --warmup 4 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_gan_skip.log 2>&1
+timeout 300 python bench.py --config discrete --phase gan --batch 32 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_discrete.log 2>&1
+timeout 300 python bench.py --config v3 --phase gan --batch 16 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_v3.log 2>&1
+RAVE_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_dist1.log 2>&1
+timeout 200 python tools/bench_layers.py < /dev/null > $O/layers.log 2>&1
+NIT=10 timeout 200 python tools/check_x6.py < /dev/null > $O/check_x6.log 2>&1
+timeout 100 python tools/bench_pqmf.py < /dev/null > $O/pqmf.log 2>&1
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/prof.log 2>&1 < /dev/null)
+f=$(find $O/prof -name "*.db" | head -1)
+[ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32.md 2>&1
+rm -rf $O/prof
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/profg -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/$O/profg.log 2>&1 < /dev/null)
+f=$(find $O/profg -name "*.db" | head -1)
+[ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32_graph.md 2>&1
+rm -rf $O/profg
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1 < /dev/null)
+  python tools/pmc_summary.py $(find $O/pmc_$c -name "*.db" | head -1) > $O/pmc_$c.txt 2>&1
+done
+python tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) $O/pmc_traffic.json > /dev/null 2>&1
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+for w in v2 encodec descript; do N=32; [ $w = v2 ] && N=64; WHICH=$w N=$N timeout 300 python tools/bench_disc2d.py < /dev/null > $O/disc_$w.log 2>&1; done
+for f in bench_n1 bench_n1_eager bench_gan bench_gan_skip bench_discrete bench_v3 bench_dist1; do echo "== $f"; grep "^{" $O/$f.log | tail -1 | cut -c1-330; done
+tail -2 $O/layers.log; tail -1 $O/check_x6.log; grep fold $O/pqmf.log; head -8 $O/kernel_stats_step_b32.md; tail -1 $O/kernel_stats_step_b32.md; tail -1 $O/kernel_stats_step_b32_graph.md
+grep "TOTAL\|fwd+bwd" $O/disc_v2.log $O/disc_encodec.log $O/disc_descript.log

@@ -5,7 +5,7 @@ import json, re, sqlite3, sys
 from collections import defaultdict
 
 FAMILIES = {"pqmf": ("pqmf_",), "conv_igemm(fwd+dgrad)": ("conv_x6_kernel", "conv_igemm_dma_kernel", "conv_igemm_kernel"),
-            "conv_wgrad": ("wgrad_dma_kernel", "wgrad_kernel")}
+            "conv_wgrad": ("wgrad_dma_kernel", "wgrad_kernel", "wgrad_x6_kernel")}
 
 
 def per_family(db, counter):
@@ -33,7 +33,7 @@ def main(fetch_db, write_db, out):
         fa, wa = sf / nf, sw / nw
         res[fam] = {"launches": nf, "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa, "hbm_bytes_per_launch": (2 * fa + wa) * 1024}
     res["_provenance"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py "
-                          "--steps 2 --warmup 1` (v2, batch 32 x 65536, VAE phase), round 1, tools/pmc_traffic.sh; bytes = "
+                          "--steps 2 --warmup 1` (v2, batch 32 x 65536, VAE phase), round 2, tools/final_measure.sh; bytes = "
                           "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of a wide coalesced read (calibrated on a "
                           "256 MiB copy: FETCH 128 MiB, WRITE 256 MiB); the factor for the LDS-DMA reads of these kernels is "
                           "uncalibrated, so the read side is an upper-bound estimate")
