@@ -55,6 +55,24 @@ def test_descriptor_queries_and_errors():
         L.check(rc, "pack")
 
 
+def test_mfma_kernels_use_no_scratch():
+    """The bf16x6 / LDS-DMA conv and weight-gradient kernels must keep their accumulators in registers: the code
+    objects' metadata (private segment size, spill counts) is read back from the built library."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location(
+        "kernel_resources", Path(__file__).resolve().parents[1] / "tools" / "kernel_resources.py")
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.kernels()
+    assert any("conv_x6_kernel" in k["name"] for k in ks) and any("wgrad_x6_kernel" in k["name"] for k in ks)
+    bad = kr.scratch_kernels()
+    assert not bad, bad
+    for k in ks:
+        if "conv_x6_kernel" in k["name"]:
+            assert k["vgpr"] + k["agpr"] <= 256, k      # two workgroups of four waves per CU
+
+
 def test_get_padding_matches_cached_conv_rule():
     from rave_amd import cc
     import rave_oracle as O
