@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must be imported first: librave_hip.so binds to the libamdhip64 torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librave_hip.so")
+# RAVE_HIP_LIB: diagnostics only (tools/x6_variants.sh loads timing-ablation builds of the same ABI)
+LIB_PATH = os.environ.get("RAVE_HIP_LIB") or os.path.join(_HERE, "librave_hip.so")
 
 ACT_NONE, ACT_LEAKY, ACT_SNAKE = 0, 1, 2
 

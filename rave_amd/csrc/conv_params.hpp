@@ -46,7 +46,6 @@ struct ConvP {
     int x6_P;                                  // positions (16-byte fragments) per (octet, piece) plane of the B tile in LDS
     int x6_a_units, x6_b_units;                // 16-byte units of one A stage / one B stage in LDS
     int x6_nu;                                 // steps (taps or tap groups) per K chunk
-    int x6_abl;                                // ablation bits for tools/check_x6.py (RH_X6_ABL); 0 in production
     long ph_q2ofs[kMaxPhases];                 // first fragment (16-byte units) of each phase in wq
     long x6_wofs;                              // floats between wp and the bf16x6 section of the packed operand
     int nphase;

@@ -100,7 +100,8 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     pl->part_bytes = pl->ksplit > 1 ? (int64_t)pl->ksplit * p.part_stride * (int64_t)sizeof(float) : 0;
     const unsigned long long in_b = 4ull * p.B * p.C * (unsigned long long)p.in_row;
     const unsigned long long row_span = (unsigned long long)p.M * (unsigned long long)p.out_row;
-    return in_b < 0x7fffffffull && (unsigned long long)p.wq_bytes < 0x7fffffffull && row_span < 0x7fffffffull;
+    const unsigned long long out_b = 4ull * (unsigned long long)p.part_stride;     // the epilogue's buffer descriptors
+    return in_b < 0x7fffffffull && (unsigned long long)p.wq_bytes < 0x7fffffffull && row_span < 0x7fffffffull && out_b < 0x7fffffffull;
 }
 
 }  // namespace
@@ -122,10 +123,6 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
         pl.chunks_per_split = (q.C * q.is) >> 4;
     }
     q.in_bytes = (unsigned)(4ull * q.B * q.C * (unsigned long long)q.in_row);
-    {
-        const char* e = getenv("RH_X6_ABL");
-        q.x6_abl = e ? atoi(e) : 0;
-    }
     q.part = (float*)ws;
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;
