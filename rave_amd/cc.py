@@ -165,10 +165,17 @@ class Conv2dK1(nn.Conv2d):
                 or self.dilation != (1, 1) or self.padding_mode != "zeros"):
             raise NotImplementedError("rave_amd.cc.Conv2dK1 supports kernel (k,1), stride (s,1), padding (p,0)")
 
-    def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, period: Optional[int] = None):
+    def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, period: Optional[int] = None,
+                period_major: bool = False):
         """``period`` set: x is the UNFOLDED (B, C, T) waveform; MultiPeriodDiscriminator.fold
         (zero pad to a multiple of the period + reshape, rave/discriminator.py:192-195) happens
-        inside the kernel."""
+        inside the kernel.  ``period_major``: x is (B * W, C, H) -- the (B, C, H, W) plane stored with the period
+        axis outermost -- and the (k,1) convolution is a plain 1-D one over H (discriminator.ConvNet)."""
+        if period_major:
+            g = ConvGeom(stride=self.stride[0], dilation=1, pad_left=self.padding[0], pad_right=self.padding[0],
+                         act=act, slope=slope)
+            w, wg = _wn_pair(self)
+            return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg, prepacked=getattr(self, "_prepacked", None))
         inner = period if period is not None else x.shape[3]
         g = ConvGeom(stride=self.stride[0], dilation=1, pad_left=self.padding[0], pad_right=self.padding[0],
                      act=act, slope=slope, inner=inner, fold=period is not None)

@@ -60,6 +60,8 @@ class ConvNet(nn.Module):
         self.net = nn.Sequential(*net)
 
     def forward(self, x, period=None):
+        if period is not None and _period_major():
+            return self._forward_period_major(x, int(period))
         features = []
         act, slope = ACT_NONE, 0.0
         first = True
@@ -75,6 +77,37 @@ class ConvNet(nn.Module):
             act, slope = ACT_NONE, 0.0
             features.append(x)
         return features
+
+
+    def _forward_period_major(self, x, period: int):
+        """MultiPeriodDiscriminator.fold (rave/discriminator.py:192-195) with the period axis stored OUTERMOST:
+        the (B, C, H, W) plane lives as (B * W, C, H), so that every (k,1) convolution of the stack is a plain
+        strided Conv1d over contiguous rows -- the geometry the bf16x6 forward / data-gradient / weight-gradient
+        kernels take (with W innermost the strided layers and every weight gradient stayed on the f32-MFMA kernels:
+        25 of 82 ms of the v2 discriminator pass).  The feature maps handed back are (B, C, H, W) VIEWS of those
+        tensors: same shapes and values as the reference's, no copy; elementwise losses keep the layout, so the
+        gradients arrive period-major as well."""
+        b, c, t = x.shape
+        pad = (-t) % period
+        if pad:
+            x = nn.functional.pad(x, (0, pad))
+        h = x.shape[-1] // period
+        x = x.view(b, c, h, period).permute(0, 3, 1, 2).contiguous().view(b * period, c, h)
+        features = []
+        act, slope = ACT_NONE, 0.0
+        for layer in self.net:
+            if isinstance(layer, nn.LeakyReLU):
+                act, slope = ACT_LEAKY, float(layer.negative_slope)   # fused into the next conv
+                continue
+            x = layer(x, act=act, slope=slope, period_major=True)
+            act, slope = ACT_NONE, 0.0
+            features.append(x.view(b, period, x.shape[1], x.shape[2]).permute(0, 2, 3, 1))
+        return features
+
+
+def _period_major() -> bool:
+    import os
+    return os.environ.get("RH_MPD_PERIOD_MAJOR", "1") != "0"
 
 
 class MultiScaleDiscriminator(nn.Module):

@@ -56,10 +56,10 @@ def spy(kind, d, fn):
     return orig(kind, d, fn)
 
 
-def spy1(kind, d, fn):      # (k,1) convs routed to the 1-D kernels: H = l_in, W = inner
-    key = (kind + "(1d)", d.c_in, d.c_out, d.l_in, d.inner, d.kernel, 1, d.stride, 1, d.dilation, 1)
+def spy1(kind, d, fn, has_bias=False, has_add=False):      # (k,1) convs routed to the 1-D kernels: H = l_in, W = inner
+    key = ("(1d)", d.c_in, d.c_out, d.l_in, d.inner, d.kernel, 1, d.stride, 1, d.dilation, 1)
     recs.append(key)
-    return orig1(kind, d, fn)
+    return orig1(kind, d, fn, has_bias, has_add)
 
 
 ops._launch2, ops._launch = spy, spy1
@@ -69,6 +69,8 @@ rec = ops.profile_end()
 ops._launch2, ops._launch = orig, orig1
 agg = OrderedDict()
 for key, (kind, fl, by, ms) in zip(recs, rec):
+    if key[0] == "(1d)":       # the recorded kind carries the kernel family tag ([x6] / [f32])
+        key = (kind + "(1d)",) + key[1:]
     a = agg.setdefault(key, [0, 0.0, 0.0])
     a[0] += 1; a[1] += fl; a[2] += ms
 tot = {}
