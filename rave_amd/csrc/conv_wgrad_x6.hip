@@ -16,6 +16,15 @@
 // Both operands need the conversion (the forward kernel gets its weights pre-split), ~4 VALU instructions per MFMA, so
 // this kernel lives off the overlap of one workgroup's conversion with the other's MFMAs (2 workgroups per CU).
 // K is split over (batch, position) ranges; the partial sums are combined in slice order by reduce_partials_kernel.
+//
+// Measured (C = 192 k = 3 layer, 83 us; ablation builds): MFMA + barriers alone 36 us of loop, loads + conversion alone
+// 33 us, together 58 us -- the phases do not overlap, and no schedule made them: wave priorities (s_setprio by wave slot
+// / block parity) changed nothing; a barrier ping-pong of two 4-wave teams in one workgroup (one multiplies while the
+// other converts) was 1.2 ... 2x slower; converting the next step INSIDE the MFMA sequence of the same wave (two LDS
+// stages, 16-position steps, sched_group_barrier interleave: 1 MFMA + 6 VALU) gained 3 % on long rows and lost up to
+// 40 % on short ones.  The probe tools/probe/mfma_valu_overlap.hip shows why: on this SIMD the time of a VALU
+// instruction ADDS to the MFMA time whichever wave issues it (MFMA alone 34-40 cycles, + 6 VALU = 46, two such waves
+// 90 per pair).  What pays is fewer VALU instructions per sample.
 #include <cstdlib>
 #include <mutex>
 #include "conv_params.hpp"
@@ -40,27 +49,25 @@ struct Wx6P {
     int off[kMaxTaps];
 };
 
-__device__ __forceinline__ void split3(float x, unsigned& a, unsigned& b, unsigned& c) {
-    a = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(a);
-    b = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(b);
-    c = __float_as_uint(r2) & 0xffff0000u;
-}
-
+// LeakyReLU (slope in [0, 1]; 1 = none) + exact 3-way bf16 split of 8 samples -> three 16-byte fragments, ~7.5 VALU
+// instructions per sample: max(x, slope x), two mask / subtract rounds, one byte permute per packed pair.  VALU work
+// is NOT free next to the matrix cores on this chip (tools/probe/mfma_valu_overlap.hip: an MFMA + 6 VALU take 46 cycles
+// against 40 for the MFMA alone, in one wave or across two) -- every instruction saved here is matrix time.
 __device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* dst, int piece_stride) {
     unsigned h[3][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        float x = v[i];
-        x = x > 0.f ? x : x * slope;
-        split3(x, h[0][i], h[1][i], h[2][i]);
+        const float x = fmaxf(v[i], v[i] * slope);
+        h[0][i] = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(h[0][i] & 0xffff0000u);
+        h[1][i] = __float_as_uint(r1);
+        h[2][i] = __float_as_uint(r1 - __uint_as_float(h[1][i] & 0xffff0000u));
     }
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
         u32x4 pk;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
+        for (int k = 0; k < 4; ++k) pk[k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);   // high halves
         dst[s3 * piece_stride] = pk;
     }
 }
@@ -244,6 +251,8 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     if (e && atoi(e) == 0) return false;
     if (w.inner != 1 || w.T > kMaxTaps || w.B <= 0 || w.r_row <= 0) return false;
     if ((w.r_act != RH_ACT_NONE && w.r_act != RH_ACT_LEAKY) || (w.s_act != RH_ACT_NONE && w.s_act != RH_ACT_LEAKY)) return false;
+    // the conversion applies LeakyReLU as max(x, slope x)
+    if ((w.r_act == RH_ACT_LEAKY && !(w.r_slope >= 0.f && w.r_slope <= 1.f)) || (w.s_act == RH_ACT_LEAKY && !(w.s_slope >= 0.f && w.s_slope <= 1.f))) return false;
     if (w.M < 32 || (long)w.C * w.T < 64) return false;            // tiny GEMMs (first discriminator layers): f32 kernels
     // Measured per layer (profiles/round2_layer_table_b32.txt): 1.2x ... 1.6x over the f32-MFMA kernel (wgrad_dma_kernel)
     // wherever the weight tensor offers a few output tiles -- everything but the <= 96-row layers on long sequences

@@ -23,6 +23,7 @@ bool x6_enabled() {
 bool plan_x6(ConvP& p, X6Plan* pl) {
     if (!x6_enabled() || p.x6_mode == 0 || p.x6_mode != p.is) return false;
     if (p.in_act == RH_ACT_SNAKE || p.epi_act == RH_ACT_SNAKE) return false;
+    if (p.in_act == RH_ACT_LEAKY && !(p.in_slope >= 0.f && p.in_slope <= 1.f)) return false;      // applied as max(x, slope x)
     {   // epilogue operand combinations the kernel carries a specialised copy for (bit 0 bias, 1 derivative, 2 add,
         // 3 output activation); everything the modules use -- anything else takes the f32 kernels
         const int mode = (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
