@@ -522,6 +522,7 @@ extern "C" int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d) {
 extern "C" int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add) {
     ConvP p{};
     if (int e = which == 0 ? rh_conv_fill_fwd(d, &p) : rh_conv_fill_dgrad(d, &p)) return e;
+    if (which == 0 ? rh_smallc_fwd_eligible(d, has_add != 0) : rh_smallc_dgrad_eligible(d, has_add != 0)) return 2;
     alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};     // only tested against NULL / alignment by the planner
     p.in = dummy; p.wp = dummy; p.wq = reinterpret_cast<const unsigned*>(dummy);
     p.bias = has_bias ? dummy : nullptr;
@@ -539,6 +540,7 @@ extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const 
     if (d->batch == 0 || d->l_out == 0) return RH_OK;
     RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv1d_fwd: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
+    if (rh_smallc_fwd_eligible(d, residual != nullptr)) return rh_smallc_fwd(d, x, wp_fwd, bias, y, (hipStream_t)stream);
     p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
     p.wq = reinterpret_cast<const unsigned*>(wp_fwd + p.x6_wofs);
     p.in_alpha = snake_alpha; p.mul_alpha = nullptr;
@@ -556,6 +558,13 @@ extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, 
     RH_REQUIRE(dy && wp_bwd && dx, RH_ERR_INVALID, "conv1d_bwd_data: null pointer");
     RH_REQUIRE(d->act == RH_ACT_NONE || x, RH_ERR_INVALID, "conv1d_bwd_data: act needs the forward input");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_data: snake needs alpha");
+    if (rh_smallc_dgrad_eligible(d, add != nullptr)) {
+        TapPlan t;
+        if (int e = build_plan(d, 1, &t)) return e;
+        int slot_of_tap[kMaxTaps];
+        for (int i = 0; i < t.nslots; ++i) slot_of_tap[t.kk[i]] = i;
+        return rh_smallc_dgrad(d, dy, wp_bwd, slot_of_tap, dx, (hipStream_t)stream);
+    }
     p.in = dy; p.wp = wp_bwd; p.out = dx; p.bias = nullptr; p.add = add;
     p.wq = reinterpret_cast<const unsigned*>(wp_bwd + p.x6_wofs);
     p.mul_src = d->act == RH_ACT_NONE ? nullptr : x;

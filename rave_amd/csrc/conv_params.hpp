@@ -130,3 +130,14 @@ inline int rh_x6_mode(int C, int nphase, int is, int inner, int ntaps0, const in
     return is;
 }
 int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool* used);
+
+// Vector-ALU kernels for the 1- / 2-channel first layers of the discriminators (conv_smallc.hip)
+bool rh_smallc_fwd_eligible(const rh_conv1d_desc* d, bool has_residual);
+int rh_smallc_fwd(const rh_conv1d_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, hipStream_t stream);
+bool rh_smallc_dgrad_eligible(const rh_conv1d_desc* d, bool has_add);
+int rh_smallc_dgrad(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd, const int* slot_of_tap, float* dx,
+                    hipStream_t stream);
+bool rh_smallc_wgrad_eligible(const rh_conv1d_desc* d);
+int64_t rh_smallc_wgrad_workspace(const rh_conv1d_desc* d);
+int rh_smallc_wgrad(const rh_conv1d_desc* d, const float* dy, const float* x, float* dw, float* dbias, void* ws,
+                    hipStream_t stream);

@@ -577,6 +577,7 @@ extern "C" int rh_conv1d_bwd_weight_kernel_family(const rh_conv1d_desc* d) {
     if (!d || d->batch <= 0) return 0;
     WgradP p{};
     fill(d, &p);
+    if (rh_smallc_wgrad_eligible(d)) return 2;
     alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
     p.R = dummy; p.S = dummy;
     return d->act != RH_ACT_SNAKE && rh_wgrad_x6_workspace(p) >= 0 ? 1 : 0;
@@ -586,6 +587,7 @@ int64_t rh_wgrad_workspace(const rh_conv1d_desc* d) {
     WgradP p{};
     fill(d, &p);
     const int64_t bias = rh_bias_grad_workspace(d->c_out);
+    if (rh_smallc_wgrad_eligible(d)) return bias + rh_smallc_wgrad_workspace(d);
     if (d->act != RH_ACT_SNAKE) {      // exact f32 on the bf16 matrix cores (conv_wgrad_x6.hip) when the geometry fits
         const int64_t x6 = rh_wgrad_x6_workspace(p);
         if (x6 >= 0) return bias + x6;
@@ -603,6 +605,12 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     else                { p.R = x; p.S = dy; p.r_alpha = alpha; p.s_alpha = nullptr; }
     const long nw = (long)p.M * p.C * p.T;
     const int64_t bias_ws = rh_bias_grad_workspace(d->c_out);
+    if (rh_smallc_wgrad_eligible(d)) {       // 1- / 2-channel first layers: vector-ALU kernel, bias gradient included
+        const int64_t need = rh_smallc_wgrad_workspace(d);
+        RH_REQUIRE(ws && ws_bytes >= need, RH_ERR_WORKSPACE, "conv1d_bwd_weight: workspace %lld B < %lld B",
+                   (long long)ws_bytes, (long long)need);
+        return rh_smallc_wgrad(d, dy, x, dw, dbias, ws, stream);
+    }
     if (dbias && d->batch > 0) {
         RH_REQUIRE(ws && ws_bytes >= bias_ws, RH_ERR_WORKSPACE, "conv1d_bwd_weight: workspace %lld B < %lld B",
                    (long long)ws_bytes, (long long)bias_ws);

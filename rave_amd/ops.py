@@ -45,14 +45,18 @@ def _conv_cost(d: "L.ConvDesc"):
     return flops, 4.0 * (x_elems + y_elems + w_elems)
 
 
+# rh_conv1d_kernel_family: 0 f32-input MFMA, 1 bf16x6 MFMA, 2 vector-ALU first-layer kernels (conv_smallc.hip)
+_FAMILY = {0: "[f32]", 1: "[x6]", 2: "[valu]"}
+
+
 def _launch(kind: str, d, fn, has_bias=False, has_add=False):
     if _PROFILE is None:
         return fn()
     if kind in ("conv_fwd", "conv_dgrad"):   # which instruction does this launch issue?
         fam = L.lib.rh_conv1d_kernel_family(C.byref(d), 0 if kind == "conv_fwd" else 1, int(has_bias), int(has_add))
-        kind += "[x6]" if fam == 1 else "[f32]"
+        kind += _FAMILY.get(fam, "[f32]")
     elif kind == "conv_wgrad":
-        kind += "[x6]" if L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(d)) == 1 else "[f32]"
+        kind += _FAMILY.get(L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(d)), "[f32]")
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -187,6 +187,55 @@ def test_conv1d_fwd_and_grads_vs_cpu(dev, ops, case):
         assert rel_l2(bg.grad, br.grad) < TOL_OP
 
 
+SMALLC_CASES = [
+    # (B, Cin, Cout, L, k, stride, pad, bias)   first discriminator layers (rave/discriminator.py:77-100)
+    (3, 1, 96, 4099, 15, 4, 7, True),       # MultiScaleDiscriminator, ragged length
+    (4, 1, 96, 1490, 5, 4, 2, True),        # MultiPeriodDiscriminator row (period-major), odd length
+    (2, 2, 64, 2050, 15, 4, 7, False),      # stereo
+    (2, 2, 32, 777, 5, 3, 2, True),         # stride 3 (descript period nets), stereo
+    (5, 1, 16, 300, 5, 1, 2, True),         # stride 1, one position block
+    (2, 1, 100, 513, 15, 1, 7, True),       # C_out not a multiple of the row group
+]
+
+
+@pytest.mark.parametrize("case", SMALLC_CASES)
+@pytest.mark.parametrize("valu", [1, 0])
+def test_first_layer_vector_kernels_vs_cpu(dev, ops, case, valu, monkeypatch):
+    """conv_smallc.hip (C_in <= 2: forward, data gradient, weight gradient as HBM-bound vector-ALU kernels) against
+    CPU fp32, and -- RH_SMALLC=0 -- the MFMA kernels the same geometry took before; the launch hook reports which ran."""
+    from rave_amd import _lib as L
+    import ctypes as C
+    B, Ci, Co, Lx, k, s, pad, has_b = case
+    monkeypatch.setenv("RH_SMALLC", str(valu))
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Ci, Lx, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / math.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g) if has_b else None
+    geom = ops.ConvGeom(stride=s, dilation=1, pad_left=pad, pad_right=pad, act=0, slope=0.2)
+    l_out = geom.out_len(Lx, k)
+    cot = torch.randn(B, Co, l_out, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_b else None
+    y_ref = torch.nn.functional.conv1d(xr, wr, br, stride=s, padding=pad)
+    (y_ref * cot).sum().backward()
+
+    d = ops._desc(geom, B, Ci, Co, Lx, l_out, k)
+    fam = [L.lib.rh_conv1d_kernel_family(C.byref(d), 0, int(has_b), 0), L.lib.rh_conv1d_kernel_family(C.byref(d), 1, 0, 0),
+           L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(d))]
+    assert (fam == [2, 2, 2]) if valu else (2 not in fam), fam
+
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bg = b.to(dev).requires_grad_(True) if has_b else None
+    y = ops.conv1d(xg, wg, bg, geom=geom)
+    assert y.shape == y_ref.shape
+    assert rel_l2(y, y_ref) < TOL_OP
+    (y * cot.to(dev)).sum().backward()
+    assert rel_l2(xg.grad, xr.grad) < TOL_OP
+    assert rel_l2(wg.grad, wr.grad) < TOL_OP
+    if has_b:
+        assert rel_l2(bg.grad, br.grad) < TOL_OP
+
+
 CONVT_CASES = [
     # (B, Cin, Cout, L, k, stride, pad, act)
     (2, 192, 96, 64, 8, 4, 2, 1),
