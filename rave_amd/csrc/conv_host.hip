@@ -140,18 +140,56 @@ void plan_to_params(const TapPlan& t, ConvP* p) {
     for (int i = 0; i < t.nslots; ++i) p->off[i] = t.off[i];
 }
 
+// "Virtual rows": the s output phases of a transposed convolution / of the data gradient of a stride-s convolution,
+// taken as s * M GEMM rows of ONE stride-1 gather over the same input.  Phase ph reads in[q + base_ph - m] for its
+// taps m = 0 .. ntaps_ph - 1 and writes out[s q + ph]; base_ph is b0 for ph < ph*, b0 + 1 from ph* on.  With column
+// n = q for the first group and n = q + 1 for the second, every phase reads in[n + b0 - u] (u < U = max ntaps) and the
+// s outputs of a column are the CONTIGUOUS run out[s n + o0 + j], j = (ph - ph*) mod s, o0 = ph* ? ph* - s : 0 --
+// one 16-byte store per lane and row group instead of s launches' worth of 4-byte stores s elements apart.
+struct VPlan { int s, U, phstar, o0, b0, jof[kMaxPhases]; };
+bool vplan_of(const TapPlan& t, int inner, VPlan* v) {
+    static const bool on = [] { const char* e = getenv("RH_X6_VROWS"); return !(e && atoi(e) == 0); }();
+    const int s = t.nphase;
+    if (!on || (s != 2 && s != 4) || t.os != s || t.is != 1 || inner != 1 || (t.C & 15) || ((t.M * s) & 31)) return false;
+    int U = 0;
+    for (int ph = 0; ph < s; ++ph) {
+        if (t.ntaps[ph] < 1) return false;
+        for (int m = 0; m < t.ntaps[ph]; ++m)
+            if (t.off[t.tap0[ph] + m] != t.off[t.tap0[ph]] - m) return false;
+        U = U > t.ntaps[ph] ? U : t.ntaps[ph];
+    }
+    const int b0 = t.off[t.tap0[0]];
+    int phstar = 0;
+    for (int ph = 0; ph < s; ++ph) {
+        const int b = t.off[t.tap0[ph]];
+        if (b == b0 + 1) { if (!phstar) phstar = ph; }
+        else if (b != b0 || phstar) return false;          // bases must be b0 ... b0, b0+1 ... b0+1
+    }
+    v->s = s; v->U = U; v->phstar = phstar; v->b0 = b0;
+    v->o0 = phstar ? phstar - s : 0;
+    for (int ph = 0; ph < s; ++ph) v->jof[ph] = (ph - phstar + s) % s;
+    return true;
+}
+
 // bf16x6 section of a packed operand (conv_x6.hip): layout mode and size in 16-byte fragments
 int x6_mode_of(const TapPlan& t, int inner) {
     return rh_x6_mode(t.C, t.nphase, t.is, inner, t.ntaps[0], t.off, t.kk);
 }
-long x6_units(const TapPlan& t, int mode, long* ph_ofs = nullptr) {
+// fragments of the bf16x6 section(s); *vofs = first fragment of the virtual-row section (-1: none)
+long x6_units(const TapPlan& t, int mode, long* ph_ofs = nullptr, int inner = 1, long* vofs = nullptr) {
     const long Mp = round32(t.M);
+    if (vofs) *vofs = -1;
     if (mode == 0) return 0;
     if (mode == 1) {
         long u = 0;
         for (int ph = 0; ph < t.nphase; ++ph) {
             if (ph_ofs) ph_ofs[ph] = u;
             u += (long)(t.C >> 4) * t.ntaps[ph] * 6 * Mp;
+        }
+        VPlan v;
+        if (vplan_of(t, inner, &v)) {
+            if (vofs) *vofs = u;
+            u += (long)(t.C >> 4) * v.U * 6 * round32(t.M * v.s);
         }
         return u;
     }
@@ -160,9 +198,18 @@ long x6_units(const TapPlan& t, int mode, long* ph_ofs = nullptr) {
 }
 void plan_to_x6(const TapPlan& t, int inner, ConvP* p) {
     p->x6_mode = x6_mode_of(t, inner);
-    long units = x6_units(t, p->x6_mode, p->ph_q2ofs);
-    if (units * 4 >= 0x7fffffffl) { p->x6_mode = 0; units = 0; }      // same bound as the packers
+    long vofs = -1;
+    long units = x6_units(t, p->x6_mode, p->ph_q2ofs, inner, &vofs);
+    if (units * 4 >= 0x7fffffffl) { p->x6_mode = 0; units = 0; vofs = -1; }      // same bound as the packers
     p->x6_nu = p->x6_mode > 1 ? rh_cdiv(t.ntaps[0], p->x6_mode) : 0;
+    p->vs = 0;
+    p->v_s = 0;
+    if (vofs >= 0) {               // the launcher (conv_x6.hip) rewrites its copy of the parameters from these
+        VPlan v;
+        vplan_of(t, inner, &v);
+        p->v_s = v.s; p->v_q2ofs = vofs;
+        p->v_o0 = v.o0; p->v_U = v.U; p->v_b0 = v.b0;
+    }
     p->x6_wofs = (long)t.nslots * t.C * round32(t.M);
     p->wq_bytes = units * 16 < 0xffffffffl ? (unsigned)(units * 16) : 0xffffffffu;
 }
@@ -240,7 +287,35 @@ __device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds 
                 const long unit = (long)q.q2a[slot] + (long)(cb >> 4) * q.q2n[slot] + (long)(((cb >> 3) & 1) * 3) * q.Mp + m0 + ml;
                 emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4);
             }
-        } else if (q.wq && q.x6_mode > 1) {
+        }
+        if (q.wq && q.x6_vs > 1) {         // second section: virtual rows
+            const int vs = q.x6_vs;
+            for (int e = tid; e < ns * 128; e += 256) {
+                const int ml = e & 31, oct = (e >> 5) & 3, sl = e >> 7;
+                const int cb = c0 + oct * 8;
+                const int r = (m0 + ml) * vs + q.q2j[s0 + sl];
+                if (cb >= q.C || r >= q.x6_Mvp) continue;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = lds[(sl * 32 + oct * 8 + i) * 33 + ml];
+                const int slot = s0 + sl;
+                const long unit = q.x6_vofs + q.vq2a[slot] + (long)(cb >> 4) * q.x6_U * 6 * q.x6_Mvp + (long)(((cb >> 3) & 1) * 3) * q.x6_Mvp + r;
+                emit_fragment(v, q.wq + unit * 4, (long)q.x6_Mvp * 4);
+            }
+            if (s0 == 0) {         // (row group j, tap u) pairs no slot covers: phases with fewer taps than the longest
+                const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int e = tid; e < q.vz_n * 128; e += 256) {
+                    const int ml = e & 31, oct = (e >> 5) & 3, zi = e >> 7;
+                    const int cb = c0 + oct * 8;
+                    const int r = (m0 + ml) * vs + q.vz_j[zi];
+                    if (cb >= q.C || r >= q.x6_Mvp) continue;
+                    const long unit = q.x6_vofs + (long)q.vz_u[zi] * 6 * q.x6_Mvp + (long)(cb >> 4) * q.x6_U * 6 * q.x6_Mvp +
+                                      (long)(((cb >> 3) & 1) * 3) * q.x6_Mvp + r;
+                    emit_fragment(zero, q.wq + unit * 4, (long)q.x6_Mvp * 4);
+                }
+            }
+        }
+        if (q.wq && q.x6_mode > 1) {
             const int IS = q.x6_mode, cpc = 16 / IS, nvc = 32 / cpc;
             const int nug = (ns + IS - 1) / IS;                    // s0 is a multiple of IS (kPackSlots % IS == 0)
             for (int e = tid; e < nug * nvc * 64; e += 256) {
@@ -288,10 +363,30 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
     for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
     const int mode = x6_mode_of(t, d->inner);
     long ph_ofs[kMaxPhases];
-    const long units = x6_units(t, mode, ph_ofs);
+    long vofs = -1;
+    const long units = x6_units(t, mode, ph_ofs, d->inner, &vofs);
     if (mode && units * 4 < 0x7fffffffl) {
         p->wq = reinterpret_cast<unsigned*>(wp + p->total);            // 16-byte aligned: Mp % 32 == 0
         p->x6_mode = mode;
+        if (vofs >= 0) {
+            VPlan v;
+            vplan_of(t, d->inner, &v);
+            p->x6_vs = v.s;
+            p->x6_vofs = vofs;
+            p->x6_U = v.U;
+            p->x6_Mvp = round32(t.M * v.s);
+            bool have[kMaxPhases][kMaxTaps] = {};
+            for (int ph = 0; ph < t.nphase; ++ph)
+                for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
+                    const int slot = t.tap0[ph] + tl;
+                    p->vq2a[slot] = tl * 6 * p->x6_Mvp;
+                    p->q2j[slot] = v.jof[ph];
+                    have[v.jof[ph]][tl] = true;
+                }
+            for (int j = 0; j < v.s; ++j)
+                for (int u = 0; u < v.U; ++u)
+                    if (!have[j][u]) { p->vz_j[p->vz_n] = j; p->vz_u[p->vz_n] = u; ++p->vz_n; }
+        }
         if (mode == 1) {
             for (int ph = 0; ph < t.nphase; ++ph)
                 for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
@@ -379,7 +474,7 @@ extern "C" int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which) {
     TapPlan t;
     if (build_plan(d, which, &t)) return -1;
     // + the bf16x6 section (3 x 2 bytes per K value, K padded to whole steps) for the geometries conv_x6.hip takes
-    const long units = x6_units(t, x6_mode_of(t, d->inner));
+    const long units = x6_units(t, x6_mode_of(t, d->inner), nullptr, d->inner);
     return units * 4 < 0x7fffffffl ? n32 + units * 4 : n32;
 }
 

@@ -46,6 +46,15 @@ struct ConvP {
     int x6_P;                                  // positions (16-byte fragments) per (octet, piece) plane of the B tile in LDS
     int x6_a_units, x6_b_units;                // 16-byte units of one A stage / one B stage in LDS
     int x6_nu;                                 // steps (taps or tap groups) per K chunk
+    // "virtual rows" (a second bf16x6 section behind the per-phase one, v_s = s > 1 when the packer wrote it: the s
+    // output phases of a transposed convolution / strided data gradient as s * M GEMM rows of ONE stride-1 gather;
+    // row r = m * s + j, a column's s outputs are contiguous in memory):
+    int v_s;                                   // 0 = the operand has no such section
+    long v_q2ofs;                              // its first fragment (16-byte units) in wq
+    int vs;                                    // 0 / 1 = off; s in the kernel's copy of the parameters
+    int Mr;                                    // real output channels (M = Mr * vs there)
+    int v_o0;                                  // output index of row j of column n = n * vs + v_o0 + j
+    int v_U, v_b0;                             // taps of the virtual gather, offsets b0 - u
     long ph_q2ofs[kMaxPhases];                 // first fragment (16-byte units) of each phase in wq
     long x6_wofs;                              // floats between wp and the bf16x6 section of the packed operand
     int nphase;
@@ -99,6 +108,13 @@ struct PackP {
     int x6_mode;          // 0 none; 1: step = (16-channel chunk, tap); IS > 1: step = (16/IS-channel chunk, tap group u),
                           //   k slot kappa of the block <-> channel kappa / IS, source tap u*IS + kappa % IS
     int x6_nu;            // IS > 1: tap groups per chunk = ceil(k / IS)
+    // x6_vs = s > 1: a second section ("virtual rows") at fragment x6_vofs: step = (16-channel chunk, tap u < x6_U),
+    // row r = m * s + q2j[slot], rows padded to x6_Mvp, fragment of slot = x6_vofs + vq2a[slot] + chunk * x6_U*6*x6_Mvp;
+    // (j, u) pairs no slot covers are written as zeros
+    int x6_vs, x6_U, x6_Mvp, vz_n;
+    long x6_vofs;
+    int q2j[kMaxTaps], vq2a[kMaxTaps];
+    int vz_j[2 * kMaxPhases], vz_u[2 * kMaxPhases];
     int kk[kMaxTaps];
     int q2a[kMaxTaps];    // mode 1: fragment offset of (phase of the slot, chunk 0, tap-in-phase of the slot)
     int q2n[kMaxTaps];    // mode 1: fragments per chunk in the phase of the slot (ntaps * 6 * Mp)

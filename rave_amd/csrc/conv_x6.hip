@@ -21,7 +21,37 @@ bool x6_enabled() {
 }
 
 bool plan_x6(ConvP& p, X6Plan* pl) {
-    if (!x6_enabled() || p.x6_mode == 0 || p.x6_mode != p.is) return false;
+    if (!x6_enabled() || p.x6_mode == 0) return false;
+    p.vs = 0;
+    p.Mr = p.M;
+    // Virtual rows (conv_host.hip: vplan_of; second section of the packed operand): the s output phases become s * M
+    // rows of one stride-1 gather with taps in[n + b0 - u], a column's s outputs are contiguous.  The kernel sees a
+    // plain mode-1 problem plus `vs`.  When the two phase groups have different bases the run of a column straddles
+    // two positions and the row needs ONE MORE column: taken unless that inflates the column tiles (rows of 2^k
+    // positions: 257 columns = 3 tiles of 128) -- then the per-phase section runs as before.
+    if (p.v_s > 1 && p.x6_mode == 1 && p.nphase == p.v_s && p.is == 1 && p.inner == 1) {
+        const int s = p.v_s;
+        const int extra = p.v_o0 ? 1 : 0;
+        auto tiles = [](int n) {
+            if (n >= 128) return (double)rh_cdiv(n, 128);
+            int w = 32;
+            while (w < n) w <<= 1;
+            return w / 128.0;
+        };
+        const int mode = (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
+        const bool epi_ok = mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 6;
+        if (epi_ok && tiles(p.ncols + extra) <= 1.07 * tiles(p.ncols)) {
+            p.vs = s;
+            p.M = p.Mr * s;
+            p.Mp = (p.M + 31) & ~31;
+            p.ncols += extra;
+            p.nphase = 1;
+            p.ph_ntaps[0] = p.v_U; p.ph_tap0[0] = 0; p.ph_oph[0] = 0; p.ph_q2ofs[0] = p.v_q2ofs;
+            p.ph_maxoff[0] = p.v_b0; p.ph_minoff[0] = p.v_b0 - p.v_U + 1;
+            for (int u = 0; u < p.v_U; ++u) p.off[u] = p.v_b0 - u;
+        }
+    }
+    if (p.x6_mode != p.is) return false;
     if (p.in_act == RH_ACT_SNAKE || p.epi_act == RH_ACT_SNAKE) return false;
     if (p.in_act == RH_ACT_LEAKY && !(p.in_slope >= 0.f && p.in_slope <= 1.f)) return false;      // applied as max(x, slope x)
     {   // epilogue operand combinations the kernel carries a specialised copy for (bit 0 bias, 1 derivative, 2 add,
@@ -97,10 +127,10 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     }
     pl->chunks_per_split = rh_cdiv(total_chunks, z);
     pl->ksplit = rh_cdiv(total_chunks, pl->chunks_per_split);
-    p.part_stride = (long)p.B * p.M * p.out_row;
+    p.part_stride = (long)p.B * p.Mr * p.out_row;
     pl->part_bytes = pl->ksplit > 1 ? (int64_t)pl->ksplit * p.part_stride * (int64_t)sizeof(float) : 0;
     const unsigned long long in_b = 4ull * p.B * p.C * (unsigned long long)p.in_row;
-    const unsigned long long row_span = (unsigned long long)p.M * (unsigned long long)p.out_row;
+    const unsigned long long row_span = (unsigned long long)p.Mr * (unsigned long long)p.out_row;
     const unsigned long long out_b = 4ull * (unsigned long long)p.part_stride;     // the epilogue's buffer descriptors
     return in_b < 0x7fffffffull && (unsigned long long)p.wq_bytes < 0x7fffffffull && row_span < 0x7fffffffull && out_b < 0x7fffffffull;
 }
@@ -133,6 +163,10 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
     else rh_x6_dispatch_is4(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     if (int e = rh_check_launch(what)) return e;
     *used = true;
-    if (q.ksplit > 1) return rh_splitk_finalize_launch(q, stream);
+    if (q.ksplit > 1) {            // the partial sums are laid out like the output: finalize with the caller's (real-row) view
+        ConvP f = p;
+        f.part = q.part; f.ksplit = q.ksplit; f.part_stride = q.part_stride;
+        return rh_splitk_finalize_launch(f, stream);
+    }
     return RH_OK;
 }

@@ -35,9 +35,10 @@ def test_descriptor_queries_and_errors():
     assert L.lib.rh_conv1d_packed_floats(C.byref(d), 1) == 3 * 96 * 96 * 5 // 2
     d0 = L.ConvDesc(batch=32, c_in=96, c_out=192, l_in=4096, l_out=1024, kernel=8, stride=4, dilation=1,
                     pad_left=3, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
-    # strided: phase-interleaved octets (forward), per-phase taps (data gradient) -- same size
+    # strided: phase-interleaved octets (forward); the data gradient carries two bf16x6 sections of the same size
+    # (per-phase taps and the "virtual rows" form with contiguous output runs, chosen per launch)
     assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 0) == 8 * 96 * 192 * 5 // 2
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 1) == 8 * 192 * 96 * 5 // 2
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 1) == 8 * 192 * 96 * 4
     d1 = L.ConvDesc(batch=2, c_in=1, c_out=96, l_in=4096, l_out=1024, kernel=15, stride=4, dilation=1,
                     pad_left=7, transposed=0, groups=1, inner=1, in_valid=0, act=0, act_slope=0.0)
     assert L.lib.rh_conv1d_packed_floats(C.byref(d1), 0) == 15 * 1 * 96       # C*stride % 16 != 0: f32 operand only
