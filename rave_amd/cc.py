@@ -193,7 +193,16 @@ class Conv2d(nn.Conv2d):
         if self.groups != 1 or self.padding_mode != "zeros" or isinstance(self.padding, str):
             raise NotImplementedError("rave_amd.cc.Conv2d: groups / padding_mode")
 
-    def forward(self, x, act: int = ACT_NONE, slope: float = 0.2):
+    def forward(self, x, act: int = ACT_NONE, slope: float = 0.2, period_major: bool = False):
+        if period_major:
+            # x is (B * W, C, H): the (B, C, H, W) plane with the period axis outermost; a (k,1) convolution is then a
+            # plain strided Conv1d over contiguous rows (descript MPD; see discriminator.ConvNet._forward_period_major)
+            if not (self.kernel_size[1] == 1 and self.stride[1] == 1 and self.padding[1] == 0 and self.dilation == (1, 1)):
+                raise NotImplementedError("rave_amd.cc.Conv2d: period-major layout needs a (k,1) convolution")
+            g = ConvGeom(stride=self.stride[0], dilation=1, pad_left=self.padding[0], pad_right=self.padding[0],
+                         out_act=act, out_slope=slope)
+            w, wg = _wn_pair(self)
+            return ops.conv1d(x, w, self.bias, geom=g, weight_g=wg)
         if (self.kernel_size[1] == 1 and self.stride[1] == 1 and self.padding[1] == 0 and self.dilation == (1, 1)
                 and self.stride[0] <= 8):
             # (k,1) kernels (descript MPD: up to 1024 channels on a period-wide plane): the 1-D LDS-DMA

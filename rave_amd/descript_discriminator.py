@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import cc, ops
 from .blocks import weight_norm
-from .discriminator import run_conv2d_layer
+from .discriminator import _period_major, run_conv2d_layer
 
 # frequency bands of the multi-resolution nets as fractions of the spectrum (descript_discriminator.py:115)
 BANDS = [(0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)]
@@ -58,6 +58,21 @@ class MPD(nn.Module):
     def forward(self, x):
         x = self.pad_to_period(x)
         b, c, t = x.shape
+        if _period_major():
+            # the period axis stored OUTERMOST: (B, C, H, W) lives as (B * W, C, H), every (5,1) convolution is a plain
+            # strided Conv1d over contiguous rows (the geometry the bf16x6 data- and weight-gradient kernels take; with W
+            # innermost the weight gradients of this stack -- 42 of 175 ms -- stayed on the f32-MFMA kernel).  The
+            # feature maps handed back are (B, C, H, W) views: same shapes and values as the reference's, no copy.
+            p = self.period
+            x = x.view(b, c, t // p, p).permute(0, 3, 1, 2).contiguous().view(b * p, c, t // p)
+            fmap = []
+            for layer in list(self.convs) + [self.conv_post]:
+                if isinstance(layer, nn.Sequential):
+                    x = layer[0](x, act=ops.ACT_LEAKY, slope=float(layer[1].negative_slope), period_major=True)
+                else:
+                    x = layer(x, period_major=True)
+                fmap.append(x.view(b, p, x.shape[1], x.shape[2]).permute(0, 2, 3, 1))
+            return fmap
         x = x.reshape(b, c, t // self.period, self.period)
         fmap = []
         for layer in list(self.convs) + [self.conv_post]:
