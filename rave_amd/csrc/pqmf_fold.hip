@@ -36,9 +36,20 @@ __global__ __launch_bounds__(256) void pqmf_fold_k1_kernel(const float* __restri
     const int n0 = blockIdx.x * kFr1;
     const float* __restrict__ src = in + (long)row * t_len;
     const int g0 = 16 * n0 + o0;
-    for (int s = tid; s < 16 * kFr1 + kTaps; s += 256) {
+    // all 18 loads of a thread in flight before the first LDS store (a rolled loop waits for each load in turn: the
+    // kernel then runs at 17 memory latencies, 36 us in the training step against 14 us with the waveform in cache)
+    constexpr int kSpan = 16 * kFr1 + kTaps, kLoads = (kSpan + 255) / 256;
+    float stage[kLoads];
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
+        const int s = tid + 256 * i;
         const int gi = g0 + s;
-        xs[s + (s >> 4)] = (gi >= 0 && gi < t_len) ? src[gi] : 0.f;
+        stage[i] = (s < kSpan && gi >= 0 && gi < t_len) ? src[gi] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
+        const int s = tid + 256 * i;
+        if (s < kSpan) xs[s + (s >> 4)] = stage[i];
     }
     __syncthreads();
     const float* __restrict__ hs = tab;
