@@ -313,9 +313,16 @@ def main():
                     "417 TFLOP/s f32-equivalent; f32-input MFMA kernels: 157.3); HIP events on the launch stream around "
                     "every launch of the kernel with the largest total time",
         }
-        out["kernels"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
-                              "tflops": v[1] / (v[3] * 1e-3) / 1e12, "peak_tflops": v[4] / 1e12,
-                              "frac_of_issued_peak": v[1] / (v[3] * 1e-3) / v[4]} for k, v in byk.items()}
+        out["kernels"] = {k: ({"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
+                               "tflops": v[1] / (v[3] * 1e-3) / 1e12, "peak_tflops": v[4] / 1e12,
+                               "frac_of_issued_peak": v[1] / (v[3] * 1e-3) / v[4]} if not k.endswith("[valu]") else
+                              # vector-ALU first-layer kernels (conv_smallc.hip): one pass over a C_out x L tensor
+                              {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "bound": "hbm",
+                               "algorithmic_TBps": v[2] / (v[3] * 1e-3) / 1e12, "peak_TBps": HBM_PEAK / 1e12,
+                               "frac_of_hbm_peak": v[2] / (v[3] * 1e-3) / HBM_PEAK}) for k, v in byk.items()}
+        out["roofline"]["mfma_note"] = ("frac is against the NOMINAL rate of the issued MFMA; a loop of nothing but these "
+                                        "MFMAs sustains 0.67-0.80 of it on this part, and VALU work adds to the MFMA time "
+                                        "instead of hiding under it (tools/probe/mfma_valu_overlap.hip, DESIGN.md 4.2)")
         out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
                                       "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}
