@@ -56,6 +56,34 @@ def test_descriptor_queries_and_errors():
         L.check(rc, "pack")
 
 
+def test_kernel_family_queries():
+    """Which kernel a launch takes is a pure function of the descriptor (no GPU needed): bf16x6 for the generator
+    convs and their strided / transposed relatives, the vector-ALU kernels for 1- / 2-channel first layers, f32 MFMA
+    for what neither takes; the environment switches flip them."""
+    from rave_amd import _lib as L
+    fam = lambda d, which: L.lib.rh_conv1d_kernel_family(C.byref(d), which, 0, 0)
+    unit = L.ConvDesc(batch=32, c_in=96, c_out=96, l_in=4096, l_out=4096, kernel=3, stride=1, dilation=9,
+                      pad_left=9, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
+    down = L.ConvDesc(batch=32, c_in=96, c_out=192, l_in=4096, l_out=1024, kernel=8, stride=4, dilation=1,
+                      pad_left=3, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
+    first = L.ConvDesc(batch=64, c_in=1, c_out=96, l_in=65536, l_out=16384, kernel=15, stride=4, dilation=1,
+                       pad_left=7, transposed=0, groups=1, inner=1, in_valid=0, act=0, act_slope=0.0)
+    assert [fam(unit, 0), fam(unit, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(unit))] == [1, 1, 0]
+    assert [fam(down, 0), fam(down, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(down))] == [1, 1, 1]
+    assert [fam(first, 0), fam(first, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(first))] == [2, 2, 2]
+    assert L.lib.rh_conv1d_workspace_bytes(C.byref(first)) > 0          # partial tiles of the fused weight + bias gradient
+    os.environ["RH_SMALLC"] = "0"
+    try:
+        assert 2 not in [fam(first, 0), fam(first, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(first))]
+    finally:
+        del os.environ["RH_SMALLC"]
+    os.environ["RH_CONV_X6"] = "0"
+    try:
+        assert [fam(unit, 0), fam(down, 1)] == [0, 0]
+    finally:
+        del os.environ["RH_CONV_X6"]
+
+
 def test_mfma_kernels_use_no_scratch():
     """The bf16x6 / LDS-DMA conv and weight-gradient kernels must keep their accumulators in registers: the code
     objects' metadata (private segment size, spill counts) is read back from the built library."""
