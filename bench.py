@@ -350,16 +350,6 @@ def main():
                                "hbm_roofline_frac": fb / t_fwd / HBM_PEAK,
                                "f32_mfma_frac": ff / t_fwd / F32_MFMA_PEAK,
                                "samples_per_s": args.batch * args.n_signal / t_fwd}
-        # ---- device launches of one eager step (what the hipGraph replay submits as one graph launch)
-        try:
-            from torch.profiler import profile, ProfilerActivity
-            with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                step(args.warmup + args.steps + reps, eager=True)
-                torch.cuda.synchronize()
-            out["launches_per_step"] = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
-        except Exception as exc:      # the count is a diagnostic, never a reason to lose the line
-            out["launches_per_step"] = None
-            out["launches_per_step_error"] = str(exc)[:120]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "v2":
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
     if use_ddp:
