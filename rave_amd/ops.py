@@ -702,6 +702,8 @@ class _StftDistanceFn(torch.autograd.Function):
 
 
 def stft_distance(frames_x: Tensor, frames_y: Tensor, eps: float) -> Tensor:
+    """CONTRACT: the frame tensors are SCRATCH -- the in-place hipFFT R2C call may overwrite them.  Pass tensors
+    nothing else reads afterwards (``ops.stft_frames`` output, as rave_amd.losses does) or clones."""
     return _StftDistanceFn.apply(frames_x, frames_y, eps)
 
 

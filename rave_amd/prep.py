@@ -12,6 +12,12 @@ Usage (rave_amd/model.py does this inside training_step)::
 
 Packed buffers are persistent (allocated once); a step's backward reads them before the next
 ``run()`` overwrites them (same stream).
+
+CONTRACT: the packed buffers are rewritten through raw pointers, so autograd's version counters do not see it.
+Every backward of a graph built under one ``run()`` must finish before the next ``run()``: a ``retain_graph``
+backward replayed after it would read the NEW weights against the OLD activations without any error.
+``training_step`` (forward, backward, optimizer step inside one prepare / release pair) satisfies this; code
+that keeps graphs across steps must not use WeightPrep (the modules then repack per forward into fresh tensors).
 """
 from __future__ import annotations
 
