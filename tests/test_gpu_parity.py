@@ -236,6 +236,42 @@ def test_first_layer_vector_kernels_vs_cpu(dev, ops, case, valu, monkeypatch):
         assert rel_l2(bg.grad, br.grad) < TOL_OP
 
 
+@pytest.mark.parametrize("which", ["v2", "descript"])
+def test_period_major_layout_matches_the_reference_layout(dev, which, monkeypatch):
+    """MultiPeriodDiscriminator / descript MPD keep the folded planes period-major and hand back (B, C, H, W) VIEWS
+    (rave_amd/discriminator.py: _forward_period_major): same shapes, values, input and parameter gradients as with
+    the period as the inner axis (RH_MPD_PERIOD_MAJOR=0, the reference's memory layout), ragged length included."""
+    from functools import partial
+    from rave_amd import discriminator as D, descript_discriminator as DD
+    torch.manual_seed(7)
+    if which == "v2":
+        net = D.MultiPeriodDiscriminator([2, 3, 5], partial(D.ConvNet, out_size=1, capacity=16, n_layers=3, kernel_size=(5, 1),
+                                                             stride=4, conv=torch.nn.Conv2d), n_channels=1)
+        x0 = 0.3 * torch.randn(3, 1, 4111)
+    else:
+        net = DD.MPD(period=3, n_channels=2)
+        x0 = 0.3 * torch.randn(2, 2, 2999)
+    net = net.to(dev)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RH_MPD_PERIOD_MAJOR", mode)
+        net.zero_grad(set_to_none=True)
+        x = x0.to(dev).requires_grad_(True)
+        feats = net(x)
+        if which == "v2":
+            feats = [f for sub in feats for f in sub]
+        loss = sum((f * torch.linspace(0.5, 1.5, f.shape[-2], device=dev).view(1, 1, -1, 1)).abs().mean() for f in feats)
+        loss.backward()
+        res[mode] = ([f.detach().clone() for f in feats], x.grad.clone(), [q.grad.clone() for q in net.parameters()])
+    assert [tuple(f.shape) for f in res["1"][0]] == [tuple(f.shape) for f in res["0"][0]]
+    assert not res["1"][0][1].is_contiguous() and res["0"][0][1].is_contiguous()       # views vs the reference layout
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert rel_l2(a, b) < TOL_OP
+    assert rel_l2(res["1"][1], res["0"][1]) < 1e-4
+    for a, b in zip(res["1"][2], res["0"][2]):
+        assert rel_l2(a, b) < 1e-4
+
+
 CONVT_CASES = [
     # (B, Cin, Cout, L, k, stride, pad, act)
     (2, 192, 96, 64, 8, 4, 2, 1),
