@@ -571,7 +571,7 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
 }  // namespace
 
 int64_t rh_wgrad_x6_workspace(const WgradP& w);
-int rh_wgrad_x6_launch(const WgradP& w, float* dw, void* ws, hipStream_t stream, bool* used);
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used);
 
 extern "C" int rh_conv1d_bwd_weight_kernel_family(const rh_conv1d_desc* d) {
     if (!d || d->batch <= 0) return 0;
@@ -611,7 +611,10 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
                    (long long)ws_bytes, (long long)need);
         return rh_smallc_wgrad(d, dy, x, dw, dbias, ws, stream);
     }
-    if (dbias && d->batch > 0) {
+    // Conv1d on the bf16x6 weight-gradient kernel: the bias gradient (row sums of dy) comes out of the same pass
+    const bool x6_path = d->act != RH_ACT_SNAKE && p.B > 0 && p.r_row > 0 && rh_wgrad_x6_workspace(p) >= 0;
+    const bool fuse_bias = x6_path && !d->transposed && dbias != nullptr;
+    if (dbias && d->batch > 0 && !fuse_bias) {
         RH_REQUIRE(ws && ws_bytes >= bias_ws, RH_ERR_WORKSPACE, "conv1d_bwd_weight: workspace %lld B < %lld B",
                    (long long)ws_bytes, (long long)bias_ws);
         // the first c_out*64 floats of the workspace; the split-K partials follow
@@ -632,7 +635,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
             RH_REQUIRE(x6 == 0 || (ws && ws_bytes >= x6), RH_ERR_WORKSPACE,
                        "conv1d_bwd_weight: workspace %lld B < %lld B", (long long)ws_bytes, (long long)x6);
             bool used = false;
-            if (int e = rh_wgrad_x6_launch(p, dw, ws, stream, &used)) return e;
+            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used)) return e;
             if (used) return RH_OK;
         }
     }

@@ -39,6 +39,7 @@ struct Wx6P {
     const float* R;
     const float* S;
     float* out;                 // [Z][M][N] partials (or dw itself when Z == 1)
+    float* rsum;                // [Z][M] row sums of R over the K slice = partial bias gradients (R = dy), or null
     int B, M, C, T, N;          // N = C * T
     int r_row, s_row, s_valid, is;
     float r_slope, s_slope;     // LeakyReLU slope of the operand's activation; 1 = none
@@ -174,7 +175,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
             }
         }
     };
+    // bias gradient = row sums of dy: the first column tile of every row tile adds up the samples it converts anyway
+    // (one pass over dy for weight AND bias gradient; the separate bias kernel re-read every dy tensor)
+    const bool want_rsum = p.rsum != nullptr && blockIdx.x == 0;      // uniform
+    float rs_acc[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) rs_acc[q] = 0.f;
     auto convert = [&]() {
+        if (want_rsum) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q)
+                rs_acc[q] += ((ra[q][0] + ra[q][1]) + (ra[q][2] + ra[q][3])) + ((ra[q][4] + ra[q][5]) + (ra[q][6] + ra[q][7]));
+        }
 #pragma unroll
         for (int q = 0; q < NA; ++q)
             if (adst[q] >= 0) emit(ra[q], p.r_slope, a_st + adst[q], BM);
@@ -224,6 +236,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         __syncthreads();
     }
 
+    if (want_rsum) {            // the OCT lanes of a row are neighbours: fixed-order butterfly, lane of octet 0 writes
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            float v = rs_acc[q];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            const int u = tid + 256 * q;
+            const int m = u / OCT;
+            if ((u % OCT) == 0 && m < BM && m0 + m < p.M) p.rsum[(long)z * p.M + m0 + m] = v;
+        }
+    }
     // ---- partial sums of this K slice
     float* __restrict__ outz = p.out + (long)z * p.M * p.N;
 #pragma unroll
@@ -319,16 +342,20 @@ int64_t rh_wgrad_x6_workspace(const WgradP& w) {
     Wx6P p;
     Wx6Plan pl{};
     if (!plan_wx6(w, &p, &pl)) return -1;
-    return pl.Z > 1 ? (int64_t)pl.Z * w.M * w.C * w.T * (int64_t)sizeof(float) : 0;
+    // partial weight tiles (Z > 1) + partial row sums for the fused bias gradient (always reserved)
+    return (pl.Z > 1 ? (int64_t)pl.Z * w.M * w.C * w.T : 0) * (int64_t)sizeof(float) + (int64_t)pl.Z * w.M * (int64_t)sizeof(float);
 }
 
 // Returns RH_OK with *used = false when the geometry does not fit this path.  ws must hold rh_wgrad_x6_workspace bytes.
-int rh_wgrad_x6_launch(const WgradP& w, float* dw, void* ws, hipStream_t stream, bool* used) {
+// rsum_out != null: also the row sums of R over (batch, position) -- the bias gradient when R = dy -- from the same pass
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used) {
     *used = false;
     Wx6P p;
     Wx6Plan pl{};
     if (!plan_wx6(w, &p, &pl)) return RH_OK;
     p.out = pl.Z > 1 ? (float*)ws : dw;
+    float* const rs_part = (float*)ws + (pl.Z > 1 ? (long)pl.Z * w.M * w.C * w.T : 0);
+    p.rsum = rsum_out ? (pl.Z > 1 ? rs_part : rsum_out) : nullptr;
     if (pl.wm == 1) {
         if (pl.tm == 1) go<1, 1>(p, pl, stream);
         else if (pl.tm == 2) go<2, 1>(p, pl, stream);
@@ -340,6 +367,9 @@ int rh_wgrad_x6_launch(const WgradP& w, float* dw, void* ws, hipStream_t stream,
     }
     if (int e = rh_check_launch("conv1d_bwd_weight_x6")) return e;
     *used = true;
-    if (pl.Z > 1) return rh_reduce_partials_launch((const float*)ws, dw, (long)w.M * w.C * w.T, pl.Z, stream, "conv1d_bwd_weight_reduce");
+    if (pl.Z > 1) {
+        if (int e = rh_reduce_partials_launch((const float*)ws, dw, (long)w.M * w.C * w.T, pl.Z, stream, "conv1d_bwd_weight_reduce")) return e;
+        if (rsum_out) return rh_reduce_partials_launch(rs_part, rsum_out, w.M, pl.Z, stream, "conv1d_bwd_bias_reduce");
+    }
     return RH_OK;
 }
