@@ -138,11 +138,13 @@ int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_f
 int64_t rh_conv1d_fwd_workspace_bytes(const rh_conv1d_desc* d);
 int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d);
 /* Which kernel family rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32 (which = 1) would launch for this
- * geometry and operand set: 1 = exact f32 on the bf16 matrix cores (3-way split, conv_x6_kernel), 0 = f32-input MFMA
- * kernels, < 0 = invalid descriptor.  Measurement only (bench.py prices every launch against the peak of the
+ * geometry and operand set: 1 = exact f32 on the bf16 matrix cores (3-way split, conv_x6_kernel), 2 = the HBM-bound
+ * vector-ALU kernels of the 1- / 2-channel first discriminator layers (conv_smallc.hip), 0 = f32-input MFMA kernels,
+ * < 0 = invalid descriptor.  Measurement only (bench.py prices every launch against the peak of the
  * instruction it issues); has_bias / has_add = the optional operands are non-NULL. */
 int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add);
-/* Same question for rh_conv1d_bwd_weight_f32: 1 = wgrad_x6_kernel (bf16 matrix cores), 0 = f32-input MFMA kernels. */
+/* Same question for rh_conv1d_bwd_weight_f32: 1 = wgrad_x6_kernel (bf16 matrix cores; for Conv1d it also produces the
+ * bias gradient), 2 = first-layer vector-ALU kernel (weight + bias gradient in one pass), 0 = f32-input MFMA kernels. */
 int rh_conv1d_bwd_weight_kernel_family(const rh_conv1d_desc* d);
 
 /* dx = act'(x) * conv_bwd_data(dy) + add.   `x` is the forward input (needed when act != NONE),
