@@ -236,7 +236,10 @@ int rh_smallc_fwd(const rh_conv1d_desc* d, const float* x, const float* wp_fwd, 
 }
 
 bool rh_smallc_dgrad_eligible(const rh_conv1d_desc* d, bool has_add) {
-    return smallc_enabled() && shape_ok(d) && !has_add && (d->kernel - 1 + d->stride - 1) / d->stride <= 16;
+    if (!(smallc_enabled() && shape_ok(d) && !has_add && (d->kernel - 1 + d->stride - 1) / d->stride <= 16)) return false;
+    const int kc = d->kernel * d->c_in;
+    // weights + the per-position contributions must fit the default dynamic LDS limit
+    return ((size_t)d->c_out * ((kc + 3) & ~3) + 256 * (size_t)(kc + 1)) * sizeof(float) <= 64 * 1024;
 }
 
 int rh_smallc_dgrad(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd, const int* slot_of_tap, float* dx,
