@@ -72,6 +72,19 @@ def _set_warmed_up(mod, state: bool) -> None:
         mod.warmed_up.fill_(int(state))
 
 
+def _forget_host_shadows(mod, _incompatible=None) -> None:
+    mod.__dict__.pop("_host_flags", None)
+    if "_warmed_up_host" in mod.__dict__:
+        mod._warmed_up_host = None
+
+
+def track_flag_buffers(mod) -> None:
+    """Call from the constructor of a module that shadows flag buffers on the host (``warmed_up``, ``enabled``,
+    ``inited``): a ``load_state_dict`` that reaches the module forgets the shadows, so the next forward reads the
+    loaded buffers (the reference reads them on every forward)."""
+    mod.register_load_state_dict_post_hook(_forget_host_shadows)
+
+
 def host_flag(mod, name: str) -> bool:
     """Truth value of a flag BUFFER (``DiscreteEncoder.enabled``, ``EuclideanCodebook.inited``: tensors in the reference,
     tested with ``if tensor:`` = a device-to-host sync per forward).  Read from the device as the reference does, except
@@ -402,6 +415,7 @@ class VariationalEncoder(nn.Module):
         self.encoder = encoder(n_channels=n_channels)
         self.beta = beta
         self.register_buffer("warmed_up", torch.tensor(0))
+        track_flag_buffers(self)
 
     def reparametrize(self, z, eps: Optional[torch.Tensor] = None):
         mean, scale = z.chunk(2, 1)
@@ -431,6 +445,7 @@ class WasserteinEncoder(nn.Module):
         super().__init__()
         self.encoder = encoder_cls(n_channels=n_channels)
         self.register_buffer("warmed_up", torch.tensor(0))
+        track_flag_buffers(self)
         self.noise_augmentation = noise_augmentation
 
     def compute_mean_kernel(self, x, y):
@@ -491,6 +506,7 @@ class DiscreteEncoder(nn.Module):
         self.rvq = vq_cls() if vq_cls is not None else None
         self.num_quantizers = num_quantizers
         self.register_buffer("warmed_up", torch.tensor(0))
+        track_flag_buffers(self)
         self.register_buffer("enabled", torch.tensor(0))
         self.noise_augmentation = noise_augmentation
 
@@ -646,6 +662,7 @@ class Generator(nn.Module):
         self.loud_stride = loud_stride
         self.cumulative_delay = 0
         self.register_buffer("warmed_up", torch.tensor(0))
+        track_flag_buffers(self)
 
     def set_warmed_up(self, state: bool):
         _set_warmed_up(self, state)

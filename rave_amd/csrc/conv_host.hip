@@ -385,7 +385,10 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
                 }
             for (int j = 0; j < v.s; ++j)
                 for (int u = 0; u < v.U; ++u)
-                    if (!have[j][u]) { p->vz_j[p->vz_n] = j; p->vz_u[p->vz_n] = u; ++p->vz_n; }
+                    if (!have[j][u]) {
+                        RH_REQUIRE(p->vz_n < 2 * kMaxPhases, RH_ERR_UNSUPPORTED, "conv1d_pack: too many empty (phase, tap) pairs");
+                        p->vz_j[p->vz_n] = j; p->vz_u[p->vz_n] = u; ++p->vz_n;
+                    }
         }
         if (mode == 1) {
             for (int ph = 0; ph < t.nphase; ++ph)
@@ -627,6 +630,28 @@ extern "C" int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int h
     p.mul_src = (which == 1 && d->act != RH_ACT_NONE) ? dummy : nullptr;
     if (p.B <= 0 || p.ncols <= 0 || p.M <= 0 || !rh_conv_dma_eligible(p)) return 0;
     return rh_conv_x6_workspace(p) >= 0 ? 1 : 0;
+}
+
+// Diagnostics: out8 = {family (rh_conv1d_kernel_family), tm, tn, wm, K slices, swapped accumulators, virtual rows, workgroups}
+// of the launch rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32 (which = 1) would issue for this geometry.
+extern "C" int rh_conv1d_plan_info(const rh_conv1d_desc* d, int which, int has_bias, int has_add, int32_t* out8) {
+    RH_REQUIRE(out8, RH_ERR_INVALID, "conv1d_plan_info: null output");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    ConvP p{};
+    if (int e = which == 0 ? rh_conv_fill_fwd(d, &p) : rh_conv_fill_dgrad(d, &p)) return e;
+    if (which == 0 ? rh_smallc_fwd_eligible(d, has_add != 0) : rh_smallc_dgrad_eligible(d, has_add != 0)) { out8[0] = 2; return RH_OK; }
+    alignas(16) static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+    p.in = dummy; p.wp = dummy; p.wq = reinterpret_cast<const unsigned*>(dummy);
+    p.bias = has_bias ? dummy : nullptr;
+    p.add = has_add ? dummy : nullptr;
+    p.mul_src = (which == 1 && d->act != RH_ACT_NONE) ? dummy : nullptr;
+    if (p.B <= 0 || p.ncols <= 0 || p.M <= 0 || !rh_conv_dma_eligible(p)) return RH_OK;
+    int q[7];
+    if (rh_conv_x6_plan_query(p, q)) {
+        out8[0] = 1;
+        for (int i = 0; i < 7; ++i) out8[i + 1] = q[i];
+    }
+    return RH_OK;
 }
 
 extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const float* wp_fwd,

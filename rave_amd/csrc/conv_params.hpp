@@ -55,6 +55,8 @@ struct ConvP {
     int Mr;                                    // real output channels (M = Mr * vs there)
     int v_o0;                                  // output index of row j of column n = n * vs + v_o0 + j
     int v_U, v_b0;                             // taps of the virtual gather, offsets b0 - u
+    int swap;                                  // accumulate D[position][channel]: 16-byte epilogue accesses (conv_x6_kernel.inc)
+    unsigned* ticket;                          // in-launch split-K combine: one zero-initialised counter per output tile, or null
     long ph_q2ofs[kMaxPhases];                 // first fragment (16-byte units) of each phase in wq
     long x6_wofs;                              // floats between wp and the bf16x6 section of the packed operand
     int nphase;
@@ -146,6 +148,7 @@ inline int rh_x6_mode(int C, int nphase, int is, int inner, int ntaps0, const in
     return is;
 }
 int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool* used);
+bool rh_conv_x6_plan_query(ConvP p, int* out7);
 
 // Vector-ALU kernels for the 1- / 2-channel first layers of the discriminators (conv_smallc.hip)
 bool rh_smallc_fwd_eligible(const rh_conv1d_desc* d, bool has_residual);

@@ -191,7 +191,9 @@ bool shape_ok(const rh_conv1d_desc* d) {
     return !d->transposed && d->inner == 1 && d->dilation == 1 && d->groups == 1 && d->in_valid == 0 &&
            (d->c_in == 1 || d->c_in == 2) && (d->kernel == 5 || d->kernel == 15) && d->stride >= 1 && d->stride <= 8 &&
            d->c_out >= 8 && d->c_out <= 256 && d->act == RH_ACT_NONE && d->batch > 0 && d->batch <= 65535 &&
-           d->l_out > 0 && d->l_in > 0;
+           d->l_out > 0 && d->l_in > 0 &&
+           // the data gradient's halo ceil((K-1)/s) and its `nl < 256` guard assume the window starts inside the taps
+           d->pad_left >= 0 && d->pad_left < d->kernel;
 }
 
 SmallP base(const rh_conv1d_desc* d) {

@@ -64,7 +64,7 @@ class MPD(nn.Module):
             # innermost the weight gradients of this stack -- 42 of 175 ms -- stayed on the f32-MFMA kernel).  The
             # feature maps handed back are (B, C, H, W) views: same shapes and values as the reference's, no copy.
             p = self.period
-            x = x.view(b, c, t // p, p).permute(0, 3, 1, 2).contiguous().view(b * p, c, t // p)
+            x = x.reshape(b, c, t // p, p).permute(0, 3, 1, 2).contiguous().view(b * p, c, t // p)
             fmap = []
             for layer in list(self.convs) + [self.conv_post]:
                 if isinstance(layer, nn.Sequential):

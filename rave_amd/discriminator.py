@@ -29,12 +29,16 @@ def _map_conv(conv):
             return cc.PlainConv1d
         if issubclass(base, (nn.Conv2d, cc.Conv2dK1)):
             return cc.Conv2dK1
+    # configurable references that only carry a name: an explicit allow-list (torch.nn and the cc classes) -- a
+    # cached_conv-style class with other constructor / padding semantics must not be mapped silently
     name = getattr(base, "__name__", "") or getattr(base, "__qualname__", "")
-    if name.endswith("Conv1d"):
+    mod = getattr(base, "__module__", "") or ""
+    known = mod.startswith(("torch.nn", "rave_amd.cc")) or mod in ("cached_conv", "cached_conv.convs")
+    if known and name in ("Conv1d", "PlainConv1d"):
         return cc.PlainConv1d
-    if name.endswith("Conv2d"):
+    if known and name in ("Conv2d", "Conv2dK1"):
         return cc.Conv2dK1
-    raise NotImplementedError(f"rave_amd ConvNet: conv class {conv}")
+    raise NotImplementedError(f"rave_amd ConvNet: conv class {conv} (expected torch.nn.Conv1d / torch.nn.Conv2d)")
 
 
 class ConvNet(nn.Module):
@@ -92,7 +96,7 @@ class ConvNet(nn.Module):
         if pad:
             x = nn.functional.pad(x, (0, pad))
         h = x.shape[-1] // period
-        x = x.view(b, c, h, period).permute(0, 3, 1, 2).contiguous().view(b * period, c, h)
+        x = x.reshape(b, c, h, period).permute(0, 3, 1, 2).contiguous().view(b * period, c, h)
         features = []
         act, slope = ACT_NONE, 0.0
         for layer in self.net:

@@ -76,6 +76,7 @@ class RAVE(nn.Module):
         self.num_skipped_features = num_skipped_features
         self.update_discriminator_every = update_discriminator_every
         self.beta_factor = 1.
+        self._beta_dev = None          # 0-d device copy of beta_factor read by the recorded (hipGraph) step
         self.register_buffer("receptive_field", torch.tensor([0, 0]).long())
         self.logged: Dict[str, torch.Tensor] = {}
         self._opts = None
@@ -87,6 +88,14 @@ class RAVE(nn.Module):
         # y_raw / x_raw (gen_opt.zero_grad() discards it).  Parameter trajectories are identical.
         self.skip_dead_grads = False
 
+    def beta_device(self, device) -> torch.Tensor:
+        """0-d device tensor holding ``beta_factor`` (created once, updated in place: see training_step)."""
+        if self._beta_dev is None or self._beta_dev.device != device:
+            self._beta_dev = torch.full((), float(self.beta_factor), device=device, dtype=torch.float32)
+        elif not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self._beta_dev.fill_(float(self.beta_factor))
+        return self._beta_dev
+
     def prepare_weights(self, with_discriminator: bool = False):
         """Refresh weight norm + packed weights of every conv in two launches (see rave_amd/prep.py);
         pair with release_weights().  training_step does this itself."""
@@ -96,6 +105,17 @@ class RAVE(nn.Module):
         self._prep[0].run()
         if with_discriminator:
             self._prep[1].run()
+
+    def set_phase_flags_eagerly(self) -> None:
+        """Read every buffer-derived host flag once outside a capture (so that a following capture finds them cached
+        with the CURRENT buffer values) and push the warm-up state to the blocks."""
+        from .blocks import host_flag
+        self.encoder.set_warmed_up(self.warmed_up)
+        self.decoder.set_warmed_up(self.warmed_up)
+        for mod in self.modules():
+            for name in ("enabled", "inited"):
+                if torch.is_tensor(getattr(mod, name, None)):
+                    host_flag(mod, name)
 
     def release_weights(self):
         if self._prep is not None:
@@ -246,7 +266,12 @@ class RAVE(nn.Module):
 
         loss_gen = {}
         loss_gen.update(distances)
-        if capture_safe or reg.item():
+        if capture_safe:
+            # per-step host scalars must not be baked into a recorded graph: beta_factor is changed every step by the
+            # reference's BetaWarmupCallback (rave/model.py:83-107), so the captured step reads it from a 0-d device
+            # tensor that GraphedTrainingStep refreshes (fill_) before every replay -- same f32 product as `reg * float`
+            loss_gen["regularization"] = reg * self.beta_device(reg.device)
+        elif reg.item():
             loss_gen["regularization"] = reg * self.beta_factor
         if self.warmed_up:
             loss_gen["feature_matching"] = self.weights["feature_matching"] * feature_matching_distance
@@ -305,8 +330,15 @@ class GraphedTrainingStep:
     step is within a few % of being launch-bound on the host (9.3 ms of pure CPU time per step measured).
 
     Eager ``training_step`` stays the parity path; tests assert bit-identical parameters after 8 steps of both.
-    Not usable with ``grad_sync`` (data-parallel runs keep the eager step: the collectives are issued from autograd
-    hooks).  The model must have been set up with ``configure_optimizers(capturable=True)``."""
+    The model must have been set up with ``configure_optimizers(capturable=True)``.
+
+    What a recorded step reads at REPLAY time (device memory, updated in place): parameters, optimizer state, the
+    learning rates (LinearLR), ``beta_factor`` (RAVE.beta_device, refreshed here before every replay) and the input
+    batch / noise.  What is BAKED IN at capture time: the loss ``weights``, the phase (``warmed_up``) and step kind
+    (one graph per (phase, kind) key), ``valid_signal_crop``'s receptive field, every buffer-derived host flag.
+    Data-dependent one-time initialisation cannot be recorded: a model whose RVQ codebooks are not initialised yet
+    (``EuclideanCodebook.inited == 0`` with the quantizer enabled) is refused -- run eager steps until the k-means
+    init has happened, then construct / call this class."""
 
     def __init__(self, model: "RAVE", example_batch: torch.Tensor, inject_eps: bool = False, warmup_iters: int = 3):
         self.model = model
@@ -319,9 +351,28 @@ class GraphedTrainingStep:
         self.logged = {}
 
     def _hop(self) -> int:
+        # one dry encode to learn the latent rate; train-mode side effects (v1 BatchNorm running statistics, lazily
+        # initialised buffers) are undone so that the snapshot taken before the capture is the caller's state
+        saved = {k: v.clone() for k, v in self.model.named_buffers()}
         with torch.no_grad():
             z = self.model.encode(self.x[:1])
+            for k, v in self.model.named_buffers():
+                v.copy_(saved[k])
+        _reset_host_shadows(self.model)
         return self.x.shape[-1] // z.shape[-1]
+
+    def _check_capturable(self) -> None:
+        m = self.model
+        enc = getattr(m, "encoder", None)
+        enabled = getattr(enc, "enabled", None)
+        if enabled is not None and bool(enabled):
+            for name, mod in m.named_modules():
+                inited = getattr(mod, "inited", None)
+                if torch.is_tensor(inited) and not bool(inited):
+                    raise RuntimeError(
+                        f"GraphedTrainingStep: {name}.inited == 0 -- the RVQ k-means initialisation is host-driven, "
+                        "data-dependent work that a recorded graph cannot contain; run eager training_step()s until the "
+                        "codebooks are initialised, then capture")
 
     def _key(self, batch_idx: int):
         m = self.model
@@ -335,6 +386,7 @@ class GraphedTrainingStep:
             if self.eps is not None:
                 self.eps.copy_(eps)
         if key not in self.graphs:
+            self._check_capturable()
             # a few eager iterations on a side stream first (allocator warm-up, lazy one-time initialisations),
             # restoring parameters / optimizer state afterwards so that the capture does not change the trajectory
             state = ({k: v.clone() for k, v in m.state_dict().items()},
@@ -351,18 +403,35 @@ class GraphedTrainingStep:
                 _restore_opt(o, st)
             for o in m.optimizers():
                 o.zero_grad(set_to_none=True)
+            # host shadows of flag buffers were filled by the warm-up run; the restore may have changed the buffers
+            _reset_host_shadows(m)
+            self._check_capturable()
             for mod in m.modules():          # host-side caches keyed on parameter versions (the restore bumped them)
                 if hasattr(mod, "refresh_host_caches"):
                     mod.refresh_host_caches()
+            m.set_phase_flags_eagerly()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True)
             # the capture itself does not execute anything: parameters are still the restored ones
             self.graphs[key] = (g, logged)
         g, logged = self.graphs[key]
+        m.beta_device(self.x.device)     # per-step scalar the recorded step reads from device memory
         g.replay()
+        if m._prep is not None:          # the replayed optimizer changed parameters behind the version counters
+            for pr in m._prep:
+                pr.invalidate()
         self.logged = logged
         return logged
+
+
+def _reset_host_shadows(model: nn.Module) -> None:
+    """Forget every host-side shadow of a flag buffer (blocks.host_flag / blocks._set_warmed_up): the next read goes to
+    the device again.  Needed after anything that rewrites buffers behind the modules' back (load_state_dict)."""
+    for mod in model.modules():
+        mod.__dict__.pop("_host_flags", None)
+        if "_warmed_up_host" in mod.__dict__:
+            mod._warmed_up_host = None
 
 
 def _clone_opt(opt):

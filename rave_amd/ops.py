@@ -34,6 +34,30 @@ def profile_end():
     return [(k, f, b, e0.elapsed_time(e1)) for (k, f, b, e0, e1) in rec]
 
 
+# ---- optional launch-plan log (parity tests: which template instance / K split / layout did each conv launch get?)
+_PLAN_LOG = None
+
+
+def plan_log_begin() -> None:
+    global _PLAN_LOG
+    _PLAN_LOG = []
+
+
+def plan_log_end():
+    """[(which, (c_in, c_out, kernel, stride, dilation, l_in), (family, tm, tn, wm, ksplit, swap, vrows, workgroups))]"""
+    global _PLAN_LOG
+    rec, _PLAN_LOG = _PLAN_LOG, None
+    return rec
+
+
+def _log_plan(d, which: int, has_bias: bool, has_add: bool) -> None:
+    if _PLAN_LOG is None:
+        return
+    out = (C.c_int32 * 8)()
+    L.check(L.lib.rh_conv1d_plan_info(C.byref(d), which, int(has_bias), int(has_add), out), "conv1d_plan_info")
+    _PLAN_LOG.append((which, (d.c_in, d.c_out, d.kernel, d.stride, d.dilation, d.l_in, d.transposed), tuple(out)))
+
+
 def _conv_cost(d: "L.ConvDesc"):
     """Algorithmic FLOPs and bytes of one conv launch (SURVEY.md section 8d rule: input once, output
     once, weights once, fp32; activation / padding / residual count zero)."""
@@ -110,6 +134,8 @@ def _ws(nbytes: int, device) -> Optional[Tensor]:
 
 
 def _fwd(d, x, wp, bias, alpha, residual, y, s):
+    L.ensure_counters(y.device)
+    _log_plan(d, 0, bias is not None, residual is not None)
     ws = _ws(L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)), y.device)
     return _launch("conv_fwd", d, lambda: L.lib.rh_conv1d_fwd_f32(
         C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y),
@@ -117,6 +143,8 @@ def _fwd(d, x, wp, bias, alpha, residual, y, s):
 
 
 def _dgrad(d, dy, wp, x, alpha, add, dx, s):
+    L.ensure_counters(dx.device)
+    _log_plan(d, 1, False, add is not None)
     ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
     return _launch("conv_dgrad", d, lambda: L.lib.rh_conv1d_bwd_data_f32(
         C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(dx),

@@ -75,14 +75,33 @@ class WeightPrep:
         self.total_rows, self.total_blocks = tr.value, tb.value
         self.items = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
 
-    def run(self) -> None:
+    def _versions(self):
+        return tuple((m.weight_v._version, m.weight_g._version) for m in self.mods)
+
+    def invalidate(self) -> None:
+        """Forget which parameter versions the packed buffers hold.  Needed after parameters were rewritten behind
+        autograd's version counters (a replayed hipGraph's optimizer step)."""
+        self._packed_versions = None
+
+    def run(self, force: bool = False) -> None:
+        """Refresh the packed weights -- unless no parameter changed since the last refresh (version counters of every
+        weight_v / weight_g: optimizer steps, ``load_state_dict`` and any other in-place write bump them), in which
+        case the persistent buffers are simply re-attached: a no-grad / inference forward pays the weight norm +
+        repack once, not per call.  While a hipGraph is being recorded the kernels always run (the graph must
+        contain them)."""
         if self.n == 0:
             return
         for m, b in zip(self.mods, self.bufs):
             if m.weight_v.data_ptr() != b[4] or m.weight_g.data_ptr() != b[5]:
                 raise RuntimeError("rave_amd.WeightPrep: a parameter was re-allocated; rebuild the WeightPrep")
-        L.check(L.lib.rh_prep_run_f32(self.items.data_ptr(), self.n, self.total_rows, self.total_blocks, L.stream()),
-                "prep_run")
+        capturing = torch.cuda.is_current_stream_capturing()
+        ver = self._versions()
+        if force or capturing or ver != getattr(self, "_packed_versions", None):
+            L.check(L.lib.rh_prep_run_f32(self.items.data_ptr(), self.n, self.total_rows, self.total_blocks, L.stream()),
+                    "prep_run")
+            # a recorded graph re-runs the repack at every replay, against parameters the replayed optimizer has
+            # changed without touching the version counters: never trust the cache across a capture
+            self._packed_versions = None if capturing else ver
         for m, b in zip(self.mods, self.bufs):
             m._prepacked = (b[0], b[1], b[2])
 

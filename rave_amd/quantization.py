@@ -79,6 +79,8 @@ class EuclideanCodebook(nn.Module):
         self.epsilon = epsilon
         self.threshold_ema_dead_code = threshold_ema_dead_code
         self.register_buffer("inited", torch.Tensor([not kmeans_init]))
+        from .blocks import track_flag_buffers
+        track_flag_buffers(self)
         self.register_buffer("cluster_size", torch.zeros(codebook_size))
         self.register_buffer("embed", embed)
         self.register_buffer("embed_avg", embed.clone())

@@ -1,0 +1,299 @@
+"""Parity of the BENCHMARKED dispatch.
+
+The full-width oracle tests run batch 2; bench.py runs batch 32, where other template instances of the bf16x6
+kernels (tile shapes, K splits, batch folding, layouts) and other reduction orders are launched.  These tests put the
+batch-32 dispatch itself under a comparison:
+
+* GPU vs GPU: default kernels against the exact-f32 MFMA kernels (``RH_CONV_X6=0 RH_WGRAD_X6=0``: bit-reproducible fmaf
+  chains, themselves pinned to the CPU oracle by tests/test_gpu_parity.py) -- hot-path outputs and all 112
+  generator-side parameter gradients at v2 CAPACITY 96, batch 32 x 65536;
+* the launch plans of that run differ from the batch-2 run's (rh_conv1d_plan_info);
+* the CPU-oracle comparison at batch 8;
+* the in-launch split-K combine against the finalize launch (bit-identical), the swapped accumulator layout against
+  the unswapped one;
+* hipGraph replay vs eager for BOTH GAN-phase step kinds.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import rave_oracle as O  # noqa: E402  (the checker: tests only)
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    return torch.device("cuda:0")
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _hot_path(dev, batch, sd, x, eps, cots, log_plans=False, **env):
+    """Forward + backward of PQMF -> EncoderV2 -> reparametrize -> GeneratorV2 -> PQMF^-1 under fixed cotangents."""
+    from rave_amd import model as M, ops as R
+    with _Env(**env):
+        m = M.build_v2()
+        m.load_state_dict(sd, strict=False)
+        m = m.to(dev).train()
+        if log_plans:
+            R.plan_log_begin()
+        m.prepare_weights()
+        zp, x_mb = m.encode(x, return_mb=True)
+        z, reg = m.encoder.reparametrize(zp, eps)
+        y_mb = m.decoder(z)
+        y_raw = m.decode(z)
+        torch.autograd.backward([y_raw, y_mb, reg], [cots[0], cots[1], torch.ones((), device=dev)])
+        m.release_weights()
+        torch.cuda.synchronize()
+        plans = R.plan_log_end() if log_plans else None
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    outs = dict(x_mb=x_mb.detach(), z_params=zp.detach(), y_mb=y_mb.detach(), y_raw=y_raw.detach())
+    del m
+    return outs, grads, plans
+
+
+def _inputs(dev, batch):
+    gen = torch.Generator().manual_seed(7)
+    x = O.synthetic_batch(batch, 1, 65536)
+    eps = torch.randn(batch, 128, 32, generator=gen)
+    cy_raw = torch.randn(batch, 1, 65536, generator=gen) * 1e-3
+    cy_mb = torch.randn(batch, 16, 4096, generator=gen) * 1e-3
+    return x, eps, (cy_raw, cy_mb)
+
+
+def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
+    """BASELINE configs[1] at its real size (v2, CAPACITY 96, batch 32 x 65536): the benchmarked kernels (bf16x6
+    forward / data gradient / weight gradient, swapped accumulators, in-launch split-K) against the exact-f32 MFMA
+    kernels, tensor by tensor.  Bounds: outputs and weight-direction gradients <= 2e-6 relative L2 (the 3-way split is
+    1.5x an fmaf chain; the two paths also reduce in different orders); weight-norm GAIN gradients are projections
+    <dw, v>/||v|| with heavy cancellation (tests/test_gpu_parity.py: 100x amplification) -> 2e-4."""
+    cfg = O.v2_config()
+    sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+    x, eps, cots = _inputs(dev, 32)
+    xd, ed, cd = x.to(dev), eps.to(dev), tuple(c.to(dev) for c in cots)
+    o1, g1, plans32 = _hot_path(dev, 32, sd, xd, ed, cd, log_plans=True)
+    o0, g0, _ = _hot_path(dev, 32, sd, xd, ed, cd, RH_CONV_X6=0, RH_WGRAD_X6=0)
+    worst = {"out": 0.0, "v": 0.0, "g": 0.0}
+    for k in o1:
+        e = rel_l2(o1[k], o0[k])
+        worst["out"] = max(worst["out"], e)
+        assert e < 2e-6, (k, e)
+    n = 0
+    for k in g1:
+        if not k.startswith(("encoder.", "decoder.")):
+            continue
+        e = rel_l2(g1[k], g0[k])
+        kind = "g" if k.endswith("weight_g") else "v"
+        worst[kind] = max(worst[kind], e)
+        assert e < (2e-4 if kind == "g" else 2e-6), (k, e)
+        n += 1
+    assert n == 112, n
+    assert worst["out"] > 0.0 and worst["v"] > 0.0          # two different code paths really ran
+    print(f"batch-32 x6 vs exact-f32: outputs {worst['out']:.2e}, dv {worst['v']:.2e}, dg {worst['g']:.2e}")
+
+    # ---- the batch-32 launches are not the instances the batch-2 tests exercise
+    x2, eps2, cots2 = _inputs(dev, 2)
+    _, _, plans2 = _hot_path(dev, 2, sd, x2.to(dev), eps2.to(dev), tuple(c.to(dev) for c in cots2), log_plans=True)
+    assert len(plans32) == len(plans2) == 112
+    x6_32 = [p for p in plans32 if p[2][0] == 1]
+    assert len(x6_32) >= 100, len(x6_32)                     # the bf16x6 family carries the generator side
+    differ = sum(1 for a, b in zip(plans32, plans2) if a[2][1:5] != b[2][1:5])
+    assert differ >= 20, differ                              # other tiles / K splits than at batch 2
+    assert sum(1 for p in plans32 if p[2][5] == 1) >= 90     # swapped accumulator layout on the unit-stride launches
+
+
+def test_full_width_batch8_vs_cpu_oracle(dev):
+    """The oracle comparison of tests/test_gpu_parity.py::test_v2_full_width_hot_path_forward_backward_vs_oracle raised
+    to batch 8 (fp32 CPU oracle for the outputs, fp64 for the gradients with the fp32 oracle's own deviation as the
+    yardstick), default kernels."""
+    batch = 8
+    cfg = O.v2_config()
+    sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+    x, eps, cots = _inputs(dev, batch)
+    sdr = {k: (v.clone().requires_grad_(v.is_floating_point() and not k.startswith("pqmf."))) for k, v in sd.items()}
+    out = O.rave_forward(x, sdr, cfg, eps)
+    torch.autograd.backward([out["y_raw"], out["y_mb"], out["reg"]], [cots[0], cots[1], torch.ones(())])
+    sd64 = {k: (v.double().requires_grad_(not k.startswith("pqmf.")) if v.is_floating_point() else v) for k, v in sd.items()}
+    out64 = O.rave_forward(x.double(), sd64, cfg, eps.double())
+    torch.autograd.backward([out64["y_raw"], out64["y_mb"], out64["reg"]],
+                            [cots[0].double(), cots[1].double(), torch.ones((), dtype=torch.float64)])
+    o, g, _ = _hot_path(dev, batch, sd, x.to(dev), eps.to(dev), tuple(c.to(dev) for c in cots))
+    assert rel_l2(o["x_mb"], out["x_mb"]) < 2e-5
+    for k in ("z_params", "y_mb", "y_raw"):
+        assert rel_l2(o[k], out[k]) < 1e-4, k
+    checked = 0
+    for k, v in sdr.items():
+        if not k.startswith(("encoder.", "decoder.")) or v.grad is None:
+            continue
+        g64 = sd64[k].grad
+        ref_err = rel_l2(v.grad, g64)
+        err = rel_l2(g[k], g64)
+        tol = 1e-3 if k.endswith("weight_g") else 2e-4
+        assert err < max(tol, 3.0 * ref_err), (k, err, ref_err)
+        checked += 1
+    assert checked == 112
+
+
+# split-K geometries of the v2 generator at batch 32 (deep stages) + ragged / small ones
+SPLITK_CASES = [
+    # (B, Ci, Co, L, k, stride, dil, transposed, act, residual, derivative-in-dgrad)
+    (32, 768, 768, 64, 3, 1, 3, False, 1, False),
+    (32, 768, 768, 64, 1, 1, 1, False, 1, True),
+    (32, 384, 384, 256, 3, 1, 9, False, 1, False),
+    (32, 1536, 256, 32, 3, 1, 1, False, 1, False),
+    (32, 128, 1536, 32, 3, 1, 1, False, 0, False),
+    (32, 768, 1536, 64, 4, 2, 1, False, 1, False),
+    (32, 384, 768, 256, 8, 4, 1, False, 1, False),
+    (3, 192, 192, 100, 3, 1, 1, False, 1, True),
+    (5, 96, 96, 37, 3, 1, 3, False, 1, False),          # ragged rows: the element-wise tail of the swapped layout
+    (2, 384, 192, 64, 8, 4, 1, True, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_inlaunch_splitk_and_swapped_layout_vs_reference_paths(dev, case):
+    """Forward and data gradient of split-K / swapped-layout launches three ways: default (swapped accumulators, K
+    slices combined inside the launch by the last workgroup of each tile), ``RH_X6_INLAUNCH_SPLITK=0`` (same slabs, finalize
+    launch: must be BIT-identical -- same additions in the same order) and ``RH_X6_SWAP=0`` (the D[channel][position]
+    copies: same MFMA sums per element -> bit-identical as well), and against the exact-f32 kernels (<= 2e-6)."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    B, Ci, Co, L, k, s, d, tr, act, res = case
+    gen = torch.Generator().manual_seed(123)
+    if tr:
+        geom = ConvGeom(stride=s, pad_left=s // 2, pad_right=s // 2, transposed=True, act=act, slope=0.2)
+        w = (torch.randn(Ci, Co, k, generator=gen) * 0.05).to(dev)
+    else:
+        p = (k - 1) * d
+        pl = p // 2 if s == 1 else (k - s) // 2 + (k - s) % 2
+        geom = ConvGeom(stride=s, dilation=d, pad_left=pl, pad_right=p - pl if s == 1 else (k - s) // 2, act=act, slope=0.2)
+        w = (torch.randn(Co, Ci, k, generator=gen) * 0.05).to(dev)
+    x = torch.randn(B, Ci, L, generator=gen).to(dev)
+
+    def run(**env):
+        with _Env(**env):
+            xx = x.clone().requires_grad_(True)
+            y = R.conv1d(xx, w, None, geom=geom, residual=(xx if res and Ci == Co and s == 1 else None))
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+            (gx,) = torch.autograd.grad(y, xx, gy)
+            torch.cuda.synchronize()
+            return y.detach().clone(), gx.detach().clone()
+
+    y1, g1 = run()
+    y1b, g1b = run()
+    assert torch.equal(y1, y1b) and torch.equal(g1, g1b)               # deterministic run to run
+    y2, g2 = run(RH_X6_INLAUNCH_SPLITK=0)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    y3, g3 = run(RH_X6_SWAP=0)
+    assert torch.equal(y1, y3) and torch.equal(g1, g3)
+    y0, g0 = run(RH_CONV_X6=0)
+    assert rel_l2(y1, y0) < 2e-6 and rel_l2(g1, g0) < 2e-6
+
+
+def test_weight_prep_cache_skips_the_repack_until_a_parameter_changes(dev):
+    """rave_amd.prep.WeightPrep.run(): a no-grad forward pays weight norm + repack once; any in-place parameter write
+    (optimizer step, load_state_dict) invalidates; results identical to a forced refresh."""
+    from rave_amd import model as M
+    torch.manual_seed(0)
+    m = M.build_v2(capacity=16, latent_size=16).to(dev).train()
+    x = O.synthetic_batch(2, 1, 16384).to(dev)
+    with torch.no_grad():
+        m.prepare_weights()
+        y1 = m.decode(m.encoder.reparametrize(m.encode(x), torch.zeros(2, 16, 8, device=dev))[0])
+        ver = m._prep[0]._packed_versions
+        assert ver is not None
+        m.prepare_weights()
+        assert m._prep[0]._packed_versions is ver                      # cache hit: nothing launched
+        p = next(m.encoder.parameters())
+        p.mul_(1.5)                                                    # any in-place write bumps the version
+        m.prepare_weights()
+        assert m._prep[0]._packed_versions != ver
+        y2 = m.decode(m.encoder.reparametrize(m.encode(x), torch.zeros(2, 16, 8, device=dev))[0])
+        m._prep[0].run(force=True)
+        y3 = m.decode(m.encoder.reparametrize(m.encode(x), torch.zeros(2, 16, 8, device=dev))[0])
+        m.release_weights()
+    assert not torch.equal(y1, y2)
+    assert torch.equal(y2, y3)
+
+
+def test_graphed_gan_phase_steps_are_bit_identical_to_eager(dev):
+    """GraphedTrainingStep for BOTH GAN-phase step kinds (discriminator step / generator step, one graph each,
+    rave_amd/model.py: GraphedTrainingStep._key) vs the eager steps: bit-identical generator AND discriminator
+    parameters after 8 alternating steps, with ``beta_factor`` changed between steps (read from device memory by the
+    recorded step)."""
+    from rave_amd import model as M
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = M.build_v2(capacity=16, latent_size=16, disc_capacity=16, update_discriminator_every=2).to(dev).train()
+        m.configure_optimizers(capturable=True)
+        m.warmed_up = True
+        xs = [O.synthetic_batch(2, 1, 32768, seed=70 + i).to(dev) for i in range(8)]
+        gen = torch.Generator().manual_seed(2)
+        es = [torch.randn(2, 16, 16, generator=gen).to(dev) for _ in range(8)]
+        step = M.GraphedTrainingStep(m, xs[0], inject_eps=True) if graphed else None
+        for i in range(8):
+            m.beta_factor = 0.1 + 0.2 * i                # BetaWarmupCallback (rave/model.py:83-107) moves it every step
+            if graphed:
+                step(xs[i], i, eps=es[i])
+            else:
+                m.training_step(xs[i].clone(), i, eps=es[i], capture_safe=True)
+            m.on_train_batch_end(None, None, i)
+        torch.cuda.synchronize()
+        kinds = len(step.graphs) if graphed else 2
+        return {k: v.detach().clone() for k, v in m.named_parameters()}, kinds
+
+    pe, _ = run(False)
+    pg, kinds = run(True)
+    assert kinds == 2                                    # one graph per step kind
+    for k in pe:
+        assert torch.equal(pe[k], pg[k]), k
+    torch.manual_seed(0)
+    m0 = M.build_v2(capacity=16, latent_size=16, disc_capacity=16, update_discriminator_every=2)
+    moved = {"encoder.": 0, "decoder.": 0, "discriminator.": 0}
+    for k, v in m0.named_parameters():
+        for pre in moved:
+            if k.startswith(pre) and not torch.equal(v.detach(), pe[k].cpu()):
+                moved[pre] += 1
+    assert all(v > 5 for v in moved.values()), moved     # both optimizers really ran
+
+
+def test_graphed_step_refuses_uninitialised_rvq(dev):
+    """a recorded step cannot contain the data-dependent k-means initialisation of the RVQ codebooks."""
+    from rave_amd import model as M
+    torch.manual_seed(0)
+    m = M.build_discrete(capacity=16, latent_size=16, num_quantizers=2, codebook_size=32, noise_augmentation=4,
+                         spectral=False, disc_capacity=16).to(dev).train()
+    m.encoder.enabled.fill_(1)
+    m.configure_optimizers(capturable=True)
+    x = O.synthetic_batch(2, 1, 32768).to(dev)
+    step = M.GraphedTrainingStep(m, x)
+    with pytest.raises(RuntimeError, match="inited"):
+        step(x, 0)
