@@ -15,8 +15,7 @@
  *   - return value: RH_OK (0), <0 = invalid / unsupported argument (nothing enqueued),
  *     >0 = hipError_t of the failed launch; rh_last_error() gives a thread-local message;
  *   - re-entrant: no mutable global state (forward runs on the Python thread, backward on
- *     PyTorch's autograd thread with the GIL released by ctypes) -- except the one caller-owned
- *     counter buffer of rh_set_counter_buffer(), registered once per process (one process per GPU).
+ *     PyTorch's autograd thread with the GIL released by ctypes).
  */
 #ifndef RAVE_HIP_H
 #define RAVE_HIP_H
@@ -87,12 +86,6 @@ typedef struct rh_conv1d_desc {
 int rh_version(void);
 const char* rh_last_error(void);
 
-/* Optional, once per process: n_counters (a multiple of 8192; 2^20 is plenty) zero-initialised uint32 in device memory
- * that stay allocated for the life of the process.  With it, split-K convolution launches combine their K slices inside
- * the launch (the workgroup that finishes a tile last sums the slices in slice order: deterministic) instead of through a
- * second "finalize" launch; every counter is back to zero when its launch ends.  NULL / 0 unregisters.  Not part of the
- * reference's interface: plumbing of the GPU implementation of cc.Conv1d (rave/blocks.py:96-108). */
-int rh_set_counter_buffer(void* zeroed_device_memory, int64_t n_counters);
 
 /* ---- weight preparation --------------------------------------------------------------- */
 
@@ -151,8 +144,8 @@ int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d);
  * < 0 = invalid descriptor.  Measurement only (bench.py prices every launch against the peak of the
  * instruction it issues); has_bias / has_add = the optional operands are non-NULL. */
 int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add);
-/* Diagnostics: out8 = {family, row tiles per wave, column tiles per wave, waves along the rows, K slices, swapped
- * accumulator layout, virtual rows, workgroups} of the launch rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32
+/* Diagnostics: out8 = {family, row tiles per wave, column tiles per wave, waves along the rows, K slices, input stride of the
+ * fragment layout, virtual rows, workgroups} of the launch rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32
  * (which = 1) would issue; zeros behind `family` for the non-bf16x6 families.  Lets the parity tests assert that the
  * benchmarked batch size runs other template instances than the small-batch tests. */
 int rh_conv1d_plan_info(const rh_conv1d_desc* d, int which, int has_bias, int has_add, int32_t* out8);

@@ -48,7 +48,6 @@ def _load() -> C.CDLL:
     sig = {
         "rh_version": ([], C.c_int),
         "rh_last_error": ([], C.c_char_p),
-        "rh_set_counter_buffer": ([P, I64], C.c_int),
         "rh_weight_norm_fwd_f32": ([P, P, I64, I64, P, P, P], C.c_int),
         "rh_weight_norm_bwd_f32": ([P, P, P, P, I64, I64, P, P, P], C.c_int),
         "rh_conv1d_packed_floats": ([D, C.c_int], I64),
@@ -115,18 +114,6 @@ def check(rc: int, what: str = "") -> None:
 
 def ptr(t) -> int | None:
     return None if t is None else t.data_ptr()
-
-
-_COUNTERS = None
-
-
-def ensure_counters(device) -> None:
-    """Registers the zero-initialised ticket counters of the in-launch split-K combine (rh_set_counter_buffer) the
-    first time a convolution runs on the GPU; the tensor lives as long as the process."""
-    global _COUNTERS
-    if _COUNTERS is None and not torch.cuda.is_current_stream_capturing():
-        _COUNTERS = torch.zeros(1 << 20, dtype=torch.int32, device=device)
-        check(lib.rh_set_counter_buffer(_COUNTERS.data_ptr(), _COUNTERS.numel()), "set_counter_buffer")
 
 
 def stream() -> int:

@@ -632,7 +632,7 @@ extern "C" int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int h
     return rh_conv_x6_workspace(p) >= 0 ? 1 : 0;
 }
 
-// Diagnostics: out8 = {family (rh_conv1d_kernel_family), tm, tn, wm, K slices, swapped accumulators, virtual rows, workgroups}
+// Diagnostics: out8 = {family (rh_conv1d_kernel_family), tm, tn, wm, K slices, fragment-layout input stride, virtual rows, workgroups}
 // of the launch rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32 (which = 1) would issue for this geometry.
 extern "C" int rh_conv1d_plan_info(const rh_conv1d_desc* d, int which, int has_bias, int has_add, int32_t* out8) {
     RH_REQUIRE(out8, RH_ERR_INVALID, "conv1d_plan_info: null output");

@@ -1,5 +1,4 @@
 // Host side of the bf16x6 convolution path (kernels: conv_x6_kernel.inc): tile / split-K plan and launch.
-#include <atomic>
 #include <cstdlib>
 #include "conv_params.hpp"
 
@@ -7,38 +6,6 @@ void rh_x6_dispatch_is1(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_
 void rh_x6_dispatch_is2(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
 void rh_x6_dispatch_is4(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
 int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream);
-
-// ---- ticket counters of the in-launch split-K combine (conv_x6_kernel.inc: x6_epilogue).  The buffer is the CALLER's
-// (rh_set_counter_buffer: zero-initialised device memory that stays allocated); every launch takes the next slot of
-// kSlot counters round-robin, so that launches in flight on different streams never share counters, and the workgroup
-// that draws a tile's last ticket puts the counter back to zero.  No buffer registered -> the finalize launch is used.
-namespace {
-constexpr long kSlot = 8192;
-std::atomic<unsigned*> g_counters{nullptr};
-std::atomic<long> g_slots{0};
-std::atomic<unsigned long> g_cursor{0};
-
-unsigned* take_counters(long n) {
-    unsigned* base = g_counters.load(std::memory_order_acquire);
-    const long slots = g_slots.load(std::memory_order_acquire);
-    if (!base || slots <= 0 || n > kSlot) return nullptr;
-    {   // read per call: the parity tests flip it at run time (0 = finalize launch instead of the in-launch combine)
-        const char* e = getenv("RH_X6_INLAUNCH_SPLITK");
-        if (e && atoi(e) == 0) return nullptr;
-    }
-    const unsigned long i = g_cursor.fetch_add(1, std::memory_order_relaxed);
-    return base + (long)(i % (unsigned long)slots) * kSlot;
-}
-}  // namespace
-
-extern "C" int rh_set_counter_buffer(void* zeroed_device_memory, int64_t n_counters) {
-    RH_REQUIRE(n_counters == 0 || (zeroed_device_memory && ((uintptr_t)zeroed_device_memory & 3) == 0), RH_ERR_INVALID,
-               "set_counter_buffer: null / misaligned buffer");
-    g_slots.store(0, std::memory_order_release);
-    g_counters.store((unsigned*)zeroed_device_memory, std::memory_order_release);
-    g_slots.store(zeroed_device_memory ? n_counters / kSlot : 0, std::memory_order_release);
-    return RH_OK;
-}
 
 namespace {
 
@@ -177,14 +144,12 @@ int64_t rh_conv_x6_workspace(ConvP p) {
 }
 
 // Diagnostics (rh_conv1d_plan_info): the tile shape / split a launch of this geometry would get.
-// out = {tm, tn, wm, ksplit, swap, vs, workgroups}; false = the geometry does not take this path.
+// out = {tm, tn, wm, ksplit, input stride of the fragment layout, vs, workgroups}; false = the geometry does not take this path.
 bool rh_conv_x6_plan_query(ConvP p, int* out) {
     X6Plan pl{};
     if (!plan_x6(p, &pl)) return false;
-    const int lim = p.ncols < p.out_valid ? p.ncols : p.out_valid;
-    const bool unit = p.vs <= 1 && p.os == 1 && p.inner == 1 && p.nphase == 1 && p.ph_oph[0] == 0;
     out[0] = pl.tm; out[1] = pl.tn; out[2] = pl.wm; out[3] = pl.ksplit;
-    out[4] = p.is != 1 ? 1 : (unit && lim % 4 == 0 ? 1 : 0);
+    out[4] = p.is;
     out[5] = p.vs;
     out[6] = pl.col_tiles * pl.row_tiles * p.nphase * pl.ksplit;
     return true;
@@ -204,22 +169,20 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
     q.part = (float*)ws;
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;
-    // unit-stride outputs in whole runs of four: accumulate D[position][channel] (16-byte epilogue accesses)
-    const char* swap_env = getenv("RH_X6_SWAP");      // read per call (tests): 0 = D[channel][position] copies for stride-1 layers
-    const bool swap_off = swap_env && atoi(swap_env) == 0;
-    const int lim = q.ncols < q.out_valid ? q.ncols : q.out_valid;
-    const bool unit = q.vs <= 1 && q.os == 1 && q.inner == 1 && q.nphase == 1 && q.ph_oph[0] == 0;
-    q.swap = q.is != 1 ? 1 : ((!swap_off && unit && lim % 4 == 0) ? 1 : 0);
-    if (q.is != 1 && !unit) return RH_OK;        // (plan_x6 admits strided gathers with one unit-stride output phase only)
-    const bool slabs_fit = 4ull * (unsigned long long)q.ksplit * (unsigned long long)q.part_stride < 0x7fffffffull;   // one descriptor over all slabs
-    q.ticket = (q.ksplit > 1 && q.swap && lim % 4 == 0 && slabs_fit) ? take_counters((long)pl.col_tiles * pl.row_tiles * q.nphase) : nullptr;
     dim3 grid(pl.col_tiles, pl.row_tiles, q.nphase * q.ksplit);
+    {   // experiment: phase skew between the two workgroups of a CU (one-round grids only), see conv_x6_kernel.inc
+        static const int skew_us10 = [] { const char* e = getenv("RH_X6_SKEW_US"); return e ? (int)(atof(e) * 10.0) : 0; }();
+        static const int skew_mode = [] { const char* e = getenv("RH_X6_SKEW_MODE"); return e ? atoi(e) : 0; }();
+        const long wgs = (long)grid.x * grid.y * grid.z;
+        q.skew_ticks = (skew_us10 > 0 && wgs > 256 && wgs <= 512) ? skew_us10 * 10 : 0;      // 100 ticks per microsecond
+        q.skew_mode = skew_mode;
+    }
     if (q.is == 1) rh_x6_dispatch_is1(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     else if (q.is == 2) rh_x6_dispatch_is2(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     else rh_x6_dispatch_is4(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     if (int e = rh_check_launch(what)) return e;
     *used = true;
-    if (q.ksplit > 1 && !q.ticket) {   // the partial sums are laid out like the output: finalize with the caller's (real-row) view
+    if (q.ksplit > 1) {            // the partial sums are laid out like the output: finalize with the caller's (real-row) view
         ConvP f = p;
         f.part = q.part; f.ksplit = q.ksplit; f.part_stride = q.part_stride;
         return rh_splitk_finalize_launch(f, stream);

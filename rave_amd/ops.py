@@ -44,7 +44,7 @@ def plan_log_begin() -> None:
 
 
 def plan_log_end():
-    """[(which, (c_in, c_out, kernel, stride, dilation, l_in), (family, tm, tn, wm, ksplit, swap, vrows, workgroups))]"""
+    """[(which, (c_in, c_out, kernel, stride, dilation, l_in), (family, tm, tn, wm, ksplit, input stride, vrows, workgroups))]"""
     global _PLAN_LOG
     rec, _PLAN_LOG = _PLAN_LOG, None
     return rec
@@ -56,6 +56,59 @@ def _log_plan(d, which: int, has_bias: bool, has_add: bool) -> None:
     out = (C.c_int32 * 8)()
     L.check(L.lib.rh_conv1d_plan_info(C.byref(d), which, int(has_bias), int(has_add), out), "conv1d_plan_info")
     _PLAN_LOG.append((which, (d.c_in, d.c_out, d.kernel, d.stride, d.dilation, d.l_in, d.transposed), tuple(out)))
+
+
+# ---- optional shadow check (parity tests): every conv launch is repeated on the exact-f32 MFMA kernels (RH_CONV_X6=0 /
+# RH_WGRAD_X6=0: bit-reproducible fmaf chains) with the SAME operands and the relative L2 difference recorded.  Per
+# launch, so activation-gate flips cannot propagate from one layer into the comparison of the next.
+_SHADOW = None
+
+
+def shadow_check_begin() -> None:
+    global _SHADOW
+    _SHADOW = []
+
+
+def shadow_check_end():
+    """[(kind, (c_in, c_out, kernel, stride, dilation, l_in, transposed, batch), rel_l2)]"""
+    global _SHADOW
+    rec, _SHADOW = _SHADOW, None
+    return rec
+
+
+def _rel(a: Tensor, b: Tensor) -> float:
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+class _ExactF32:
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in ("RH_CONV_X6", "RH_WGRAD_X6")}
+        os.environ["RH_CONV_X6"] = "0"
+        os.environ["RH_WGRAD_X6"] = "0"
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _shadow(kind: str, d, run, outs) -> None:
+    """``run(outs2)`` repeats the launch into fresh output tensors; called after the real launch."""
+    if _SHADOW is None:
+        return
+    outs2 = [torch.empty_like(o) if o is not None else None for o in outs]
+    with _ExactF32():
+        check_rc = run(outs2)
+    L.check(check_rc, "shadow " + kind)
+    key = (d.c_in, d.c_out, d.kernel, d.stride, d.dilation, d.l_in, d.transposed, d.batch)
+    for o, o2 in zip(outs, outs2):
+        if o is not None:
+            _SHADOW.append((kind, key, _rel(o, o2)))
 
 
 def _conv_cost(d: "L.ConvDesc"):
@@ -134,21 +187,42 @@ def _ws(nbytes: int, device) -> Optional[Tensor]:
 
 
 def _fwd(d, x, wp, bias, alpha, residual, y, s):
-    L.ensure_counters(y.device)
     _log_plan(d, 0, bias is not None, residual is not None)
     ws = _ws(L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)), y.device)
-    return _launch("conv_fwd", d, lambda: L.lib.rh_conv1d_fwd_f32(
-        C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(y),
-        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s), bias is not None, residual is not None)
+
+    def run(out):
+        return L.lib.rh_conv1d_fwd_f32(C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(out),
+                                       L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s)
+
+    rc = _launch("conv_fwd", d, lambda: run(y), bias is not None, residual is not None)
+    if rc == 0:
+        _shadow("fwd", d, lambda o: run(o[0]), [y])
+    return rc
 
 
 def _dgrad(d, dy, wp, x, alpha, add, dx, s):
-    L.ensure_counters(dx.device)
     _log_plan(d, 1, False, add is not None)
     ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
-    return _launch("conv_dgrad", d, lambda: L.lib.rh_conv1d_bwd_data_f32(
-        C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(dx),
-        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s), False, add is not None)
+
+    def run(out):
+        return L.lib.rh_conv1d_bwd_data_f32(C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(out),
+                                            L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s)
+
+    rc = _launch("conv_dgrad", d, lambda: run(dx), False, add is not None)
+    if rc == 0:
+        _shadow("dgrad", d, lambda o: run(o[0]), [dx])
+    return rc
+
+
+def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s):
+    def run(o_dw, o_db):
+        return L.lib.rh_conv1d_bwd_weight_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(o_dw), L.ptr(o_db), L.ptr(ws),
+                                              nbytes, s)
+
+    rc = _launch("conv_wgrad", d, lambda: run(dw, db))
+    if rc == 0:
+        _shadow("wgrad", d, lambda o: run(o[0], o[1]), [dw, db])
+    return rc
 
 
 def _shapes(x: Tensor, weight: Tensor, g: ConvGeom):
@@ -261,8 +335,7 @@ class _ConvFn(torch.autograd.Function):
                 db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
-            L.check(_launch("conv_wgrad", d, lambda: L.lib.rh_conv1d_bwd_weight_f32(
-                dref, L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes, s)), "conv1d_bwd_weight")
+            L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
             if g is not None:
                 dw, dg = _wn_bwd(dw, v, g, norms, s)
         if alpha is not None and ctx.needs_input_grad[4]:
@@ -356,14 +429,12 @@ class _ResidualUnitFn(torch.autograd.Function):
         ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
         if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
             dw1 = torch.empty(ctx.w1shape, device=dev)
-            L.check(_launch("conv_wgrad", d1, lambda: L.lib.rh_conv1d_bwd_weight_f32(
-                r1, L.ptr(dy), L.ptr(h), L.ptr(alpha2), L.ptr(dw1), None, L.ptr(ws), nb1, s)), "unit k1 wgrad")
+            L.check(_wgrad(d1, dy, h, alpha2, dw1, None, ws, nb1, s), "unit k1 wgrad")
             if g1w is not None:
                 dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s)
         if ctx.needs_input_grad[1] or (g3w is not None and ctx.needs_input_grad[2]):
             dw3 = torch.empty(ctx.w3shape, device=dev)
-            L.check(_launch("conv_wgrad", d3, lambda: L.lib.rh_conv1d_bwd_weight_f32(
-                r3, L.ptr(dh), L.ptr(x), L.ptr(alpha0), L.ptr(dw3), None, L.ptr(ws), nb3, s)), "unit k3 wgrad")
+            L.check(_wgrad(d3, dh, x, alpha0, dw3, None, ws, nb3, s), "unit k3 wgrad")
             if g3w is not None:
                 dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s)
         if ctx.needs_input_grad[0]:

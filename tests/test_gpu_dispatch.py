@@ -4,13 +4,13 @@ The full-width oracle tests run batch 2; bench.py runs batch 32, where other tem
 kernels (tile shapes, K splits, batch folding, layouts) and other reduction orders are launched.  These tests put the
 batch-32 dispatch itself under a comparison:
 
-* GPU vs GPU: default kernels against the exact-f32 MFMA kernels (``RH_CONV_X6=0 RH_WGRAD_X6=0``: bit-reproducible fmaf
-  chains, themselves pinned to the CPU oracle by tests/test_gpu_parity.py) -- hot-path outputs and all 112
-  generator-side parameter gradients at v2 CAPACITY 96, batch 32 x 65536;
+* GPU vs GPU, launch by launch ("shadow check", rave_amd.ops.shadow_check_begin): every one of the 168 conv launches of
+  the batch-32 hot path (56 forward, 56 data gradient, 56 weight gradient) is repeated on the exact-f32 MFMA kernels
+  (``RH_CONV_X6=0 RH_WGRAD_X6=0``: bit-reproducible fmaf chains, themselves pinned to the CPU oracle by
+  tests/test_gpu_parity.py) with the SAME operands: <= 2e-6 relative L2 each;
+* end to end on the same run: hot-path outputs (<= 2e-6) and all 112 generator-side parameter gradients;
 * the launch plans of that run differ from the batch-2 run's (rh_conv1d_plan_info);
 * the CPU-oracle comparison at batch 8;
-* the in-launch split-K combine against the finalize launch (bit-identical), the swapped accumulator layout against
-  the unswapped one;
 * hipGraph replay vs eager for BOTH GAN-phase step kinds.
 """
 import os
@@ -55,7 +55,7 @@ class _Env:
                 os.environ[k] = v
 
 
-def _hot_path(dev, batch, sd, x, eps, cots, log_plans=False, **env):
+def _hot_path(dev, batch, sd, x, eps, cots, log_plans=False, shadow=False, **env):
     """Forward + backward of PQMF -> EncoderV2 -> reparametrize -> GeneratorV2 -> PQMF^-1 under fixed cotangents."""
     from rave_amd import model as M, ops as R
     with _Env(**env):
@@ -64,6 +64,8 @@ def _hot_path(dev, batch, sd, x, eps, cots, log_plans=False, **env):
         m = m.to(dev).train()
         if log_plans:
             R.plan_log_begin()
+        if shadow:
+            R.shadow_check_begin()
         m.prepare_weights()
         zp, x_mb = m.encode(x, return_mb=True)
         z, reg = m.encoder.reparametrize(zp, eps)
@@ -73,6 +75,8 @@ def _hot_path(dev, batch, sd, x, eps, cots, log_plans=False, **env):
         m.release_weights()
         torch.cuda.synchronize()
         plans = R.plan_log_end() if log_plans else None
+        if shadow:
+            plans = (plans, R.shadow_check_end())
     grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
     outs = dict(x_mb=x_mb.detach(), z_params=zp.detach(), y_mb=y_mb.detach(), y_raw=y_raw.detach())
     del m
@@ -90,15 +94,28 @@ def _inputs(dev, batch):
 
 def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
     """BASELINE configs[1] at its real size (v2, CAPACITY 96, batch 32 x 65536): the benchmarked kernels (bf16x6
-    forward / data gradient / weight gradient, swapped accumulators, in-launch split-K) against the exact-f32 MFMA
-    kernels, tensor by tensor.  Bounds: outputs and weight-direction gradients <= 2e-6 relative L2 (the 3-way split is
-    1.5x an fmaf chain; the two paths also reduce in different orders); weight-norm GAIN gradients are projections
-    <dw, v>/||v|| with heavy cancellation (tests/test_gpu_parity.py: 100x amplification) -> 2e-4."""
+    forward / data gradient / weight gradient) against the exact-f32 MFMA kernels.
+
+    Launch by launch, on identical operands: <= 2e-6 relative L2 for every output, data gradient, weight gradient and
+    bias gradient (the 3-way split is 1.5x an fmaf chain and the two kernels reduce in different orders).
+    End to end: outputs <= 2e-6; parameter gradients <= 5e-4 -- through 56 layers of backward the two runs do NOT see
+    identical operands: a LeakyReLU pre-activation within rounding of zero takes the other slope in the other run and
+    changes that element's gradient fivefold (measured 1.3e-4 on the stem weight, the far end of the chain; same
+    mechanism as tests/test_gpu_parity.py::_hinge_step_vs_oracle documents), which is why the per-launch comparison
+    above is the tight one."""
     cfg = O.v2_config()
     sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
     x, eps, cots = _inputs(dev, 32)
     xd, ed, cd = x.to(dev), eps.to(dev), tuple(c.to(dev) for c in cots)
-    o1, g1, plans32 = _hot_path(dev, 32, sd, xd, ed, cd, log_plans=True)
+    o1, g1, (plans32, shadow) = _hot_path(dev, 32, sd, xd, ed, cd, log_plans=True, shadow=True)
+    kinds = {}
+    worst_launch = 0.0
+    for kind, key, err in shadow:
+        kinds[kind] = kinds.get(kind, 0) + 1
+        worst_launch = max(worst_launch, err)
+        assert err < 2e-6, (kind, key, err)
+    assert kinds == {"fwd": 56, "dgrad": 56, "wgrad": 56}, kinds
+    assert worst_launch > 0.0                                 # two different kernels really ran
     o0, g0, _ = _hot_path(dev, 32, sd, xd, ed, cd, RH_CONV_X6=0, RH_WGRAD_X6=0)
     worst = {"out": 0.0, "v": 0.0, "g": 0.0}
     for k in o1:
@@ -112,11 +129,11 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
         e = rel_l2(g1[k], g0[k])
         kind = "g" if k.endswith("weight_g") else "v"
         worst[kind] = max(worst[kind], e)
-        assert e < (2e-4 if kind == "g" else 2e-6), (k, e)
+        assert e < 5e-4, (k, e)
         n += 1
     assert n == 112, n
-    assert worst["out"] > 0.0 and worst["v"] > 0.0          # two different code paths really ran
-    print(f"batch-32 x6 vs exact-f32: outputs {worst['out']:.2e}, dv {worst['v']:.2e}, dg {worst['g']:.2e}")
+    print(f"batch-32 x6 vs exact-f32: per launch {worst_launch:.2e}; outputs {worst['out']:.2e}, dv {worst['v']:.2e}, "
+          f"dg {worst['g']:.2e}")
 
     # ---- the batch-32 launches are not the instances the batch-2 tests exercise
     x2, eps2, cots2 = _inputs(dev, 2)
@@ -126,7 +143,6 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
     assert len(x6_32) >= 100, len(x6_32)                     # the bf16x6 family carries the generator side
     differ = sum(1 for a, b in zip(plans32, plans2) if a[2][1:5] != b[2][1:5])
     assert differ >= 20, differ                              # other tiles / K splits than at batch 2
-    assert sum(1 for p in plans32 if p[2][5] == 1) >= 90     # swapped accumulator layout on the unit-stride launches
 
 
 def test_full_width_batch8_vs_cpu_oracle(dev):
@@ -159,62 +175,6 @@ def test_full_width_batch8_vs_cpu_oracle(dev):
         assert err < max(tol, 3.0 * ref_err), (k, err, ref_err)
         checked += 1
     assert checked == 112
-
-
-# split-K geometries of the v2 generator at batch 32 (deep stages) + ragged / small ones
-SPLITK_CASES = [
-    # (B, Ci, Co, L, k, stride, dil, transposed, act, residual, derivative-in-dgrad)
-    (32, 768, 768, 64, 3, 1, 3, False, 1, False),
-    (32, 768, 768, 64, 1, 1, 1, False, 1, True),
-    (32, 384, 384, 256, 3, 1, 9, False, 1, False),
-    (32, 1536, 256, 32, 3, 1, 1, False, 1, False),
-    (32, 128, 1536, 32, 3, 1, 1, False, 0, False),
-    (32, 768, 1536, 64, 4, 2, 1, False, 1, False),
-    (32, 384, 768, 256, 8, 4, 1, False, 1, False),
-    (3, 192, 192, 100, 3, 1, 1, False, 1, True),
-    (5, 96, 96, 37, 3, 1, 3, False, 1, False),          # ragged rows: the element-wise tail of the swapped layout
-    (2, 384, 192, 64, 8, 4, 1, True, 1, False),
-]
-
-
-@pytest.mark.parametrize("case", SPLITK_CASES)
-def test_inlaunch_splitk_and_swapped_layout_vs_reference_paths(dev, case):
-    """Forward and data gradient of split-K / swapped-layout launches three ways: default (swapped accumulators, K
-    slices combined inside the launch by the last workgroup of each tile), ``RH_X6_INLAUNCH_SPLITK=0`` (same slabs, finalize
-    launch: must be BIT-identical -- same additions in the same order) and ``RH_X6_SWAP=0`` (the D[channel][position]
-    copies: same MFMA sums per element -> bit-identical as well), and against the exact-f32 kernels (<= 2e-6)."""
-    from rave_amd import ops as R
-    from rave_amd.ops import ConvGeom
-    B, Ci, Co, L, k, s, d, tr, act, res = case
-    gen = torch.Generator().manual_seed(123)
-    if tr:
-        geom = ConvGeom(stride=s, pad_left=s // 2, pad_right=s // 2, transposed=True, act=act, slope=0.2)
-        w = (torch.randn(Ci, Co, k, generator=gen) * 0.05).to(dev)
-    else:
-        p = (k - 1) * d
-        pl = p // 2 if s == 1 else (k - s) // 2 + (k - s) % 2
-        geom = ConvGeom(stride=s, dilation=d, pad_left=pl, pad_right=p - pl if s == 1 else (k - s) // 2, act=act, slope=0.2)
-        w = (torch.randn(Co, Ci, k, generator=gen) * 0.05).to(dev)
-    x = torch.randn(B, Ci, L, generator=gen).to(dev)
-
-    def run(**env):
-        with _Env(**env):
-            xx = x.clone().requires_grad_(True)
-            y = R.conv1d(xx, w, None, geom=geom, residual=(xx if res and Ci == Co and s == 1 else None))
-            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev)
-            (gx,) = torch.autograd.grad(y, xx, gy)
-            torch.cuda.synchronize()
-            return y.detach().clone(), gx.detach().clone()
-
-    y1, g1 = run()
-    y1b, g1b = run()
-    assert torch.equal(y1, y1b) and torch.equal(g1, g1b)               # deterministic run to run
-    y2, g2 = run(RH_X6_INLAUNCH_SPLITK=0)
-    assert torch.equal(y1, y2) and torch.equal(g1, g2)
-    y3, g3 = run(RH_X6_SWAP=0)
-    assert torch.equal(y1, y3) and torch.equal(g1, g3)
-    y0, g0 = run(RH_CONV_X6=0)
-    assert rel_l2(y1, y0) < 2e-6 and rel_l2(g1, g0) < 2e-6
 
 
 def test_weight_prep_cache_skips_the_repack_until_a_parameter_changes(dev):
