@@ -140,8 +140,8 @@ def main():
                     help="opt-in (NOT the headline): skip gradients the reference computes and discards "
                          "(rave_amd.model.RAVE.skip_dead_grads)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="run the eager step instead of replaying the captured hipGraph (single-GPU runs only; "
-                         "data-parallel runs are always eager: the collectives are issued from autograd hooks)")
+                    help="run the eager step instead of replaying the captured hipGraph (data-parallel runs record the "
+                         "bucket all-reduces into the same graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -197,7 +197,7 @@ def main():
     use_ddp = world > 1 or force_dist
     # (the discrete config initialises its RVQ codebooks with k-means inside its first training steps: host-driven,
     # data-dependent work that a recorded graph cannot contain -- it runs the eager step)
-    use_graph = not args.no_graph and not use_ddp and args.config != "discrete"
+    use_graph = not args.no_graph and args.config != "discrete"
     gen_opt, dis_opt = m.configure_optimizers(capturable=use_graph)
     m.warmed_up = args.phase == "gan"
     m.skip_dead_grads = bool(args.skip_dead_grads)
@@ -216,17 +216,44 @@ def main():
         x = x + a * torch.sin(6.283185307 * f0 * t + ph)
     x = x.clamp(-1, 1).to(dev)
 
-    graphed = M.GraphedTrainingStep(m, x) if use_graph else None
+    # data-parallel hooks of one step: the reducer of the optimizer that steps (index 0 generator, 1 discriminator)
+    ddp_exposed = []                      # (event before finish(), event after): communication the compute stream waits for
+
+    def grad_begin(idx):
+        (red_dis if idx == 1 else red_gen).begin()
+
+    def grad_sync(idx):
+        red = red_dis if idx == 1 else red_gen
+        timed = ddp_exposed is not None and not torch.cuda.is_current_stream_capturing() and len(ddp_exposed) < 64
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        red.finish()
+        if timed:
+            e1.record()
+            ddp_exposed.append((e0, e1))
+
+    sync_kw = dict(grad_begin=grad_begin, grad_sync=grad_sync) if use_ddp else {}
+    graphed = None
+    graph_note = None
+    if use_graph:
+        try:
+            graphed = M.GraphedTrainingStep(m, x, before_step=(bufsync.sync if use_ddp else None), **sync_kw)
+            graphed(x, 0)                 # capture now: a failure falls back to the eager step (reported)
+            torch.cuda.synchronize()
+        except Exception as e:            # noqa: BLE001 -- e.g. a collective the backend cannot record
+            if not use_ddp:
+                raise
+            graph_note = f"hipGraph capture of the data-parallel step failed ({type(e).__name__}: {e}); eager step"
+            graphed, use_graph = None, False
+            m.configure_optimizers(capturable=False)
 
     def step(i, eager=False):
         if graphed is not None and not eager:
             graphed(x, i)
         elif use_ddp:
             bufsync.sync()
-            dis_step = m.warmed_up and not (i % m.update_discriminator_every)
-            red = red_dis if dis_step else red_gen
-            red.begin()
-            m.training_step(x.detach().clone(), i, grad_sync=lambda idx: red.finish())
+            m.training_step(x.detach().clone(), i, capture_safe=use_graph, **sync_kw)
         else:
             m.training_step(x.detach().clone(), i, capture_safe=use_graph)
         m.on_train_batch_end(None, None, i)       # generator LR schedule (rave/model.py:272-274)
@@ -269,14 +296,20 @@ def main():
         "ms_per_step_median_hip_events": per_step[len(per_step) // 2] if per_step else None,
         "step_mode": "hipGraph replay (rave_amd.model.GraphedTrainingStep)" if use_graph else "eager",
     }
+    if graph_note:
+        out["step_mode_note"] = graph_note
 
-    if rank == 0 and not args.no_kernel_timing and args.config == "v2":
-        # ---- per-launch HIP-event timing of the conv kernels over instrumented replays of the step
+    rec = None
+    if not args.no_kernel_timing and args.config == "v2":
+        # ---- per-launch HIP-event timing of the conv kernels over instrumented replays of the step.  EVERY rank runs
+        # these steps (they contain the gradient all-reduce); rank 0 reports.
         reps = 2
         ops.profile_begin()
         for i in range(reps):
             step(args.warmup + args.steps + i, eager=True)     # per-launch events need the eager step
         rec = ops.profile_end()
+        fence()
+    if rank == 0 and rec is not None:
         agg = {}
         for kind, fl, by, ms in rec:
             a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
@@ -327,28 +360,38 @@ def main():
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
                                       "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}
         # ---- forward-only leg of the north-star target (PQMF + conv stacks, no_grad)
-        def fwd_once():
-            m.prepare_weights()          # weight norm + repack of all layers (part of every forward)
+        def fwd_once(force_prep):
+            if force_prep:
+                m._prep[0].invalidate()  # as if a parameter had changed: weight norm + repack of all layers
+            m.prepare_weights(reuse=True)   # unchanged parameters: the packed operands are reused (rave_amd.prep.WeightPrep.run)
             m.decode(m.encoder.reparametrize(m.encode(x))[0])
             m.release_weights()
 
-        with torch.no_grad():
+        def time_fwd(force_prep, nf=8):
             for _ in range(2):
-                fwd_once()
+                fwd_once(force_prep)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            nf = 5
             for _ in range(nf):
-                fwd_once()
+                fwd_once(force_prep)
             e1.record()
             torch.cuda.synchronize()
-            t_fwd = e0.elapsed_time(e1) * 1e-3 / nf
+            return e0.elapsed_time(e1) * 1e-3 / nf
+
+        with torch.no_grad():
+            m.prepare_weights(reuse=True)
+            t_fwd_prep = time_fwd(True)
+            t_fwd = time_fwd(False)
         fb = args.batch * V2_FWD_ACT_BYTES_PER_CLIP * (args.n_signal / 65536) + V2_WEIGHT_BYTES
         ff = 2.0 * args.batch * V2_FWD_MAC_PER_CLIP * (args.n_signal / 65536)
-        out["forward_only"] = {"ms": t_fwd * 1e3, "algorithmic_bytes": fb, "algorithmic_flop": ff,
+        out["forward_only"] = {"ms": t_fwd * 1e3, "ms_with_weight_prep": t_fwd_prep * 1e3,
+                               "note": "inference forward (no_grad): packed weights reused while no parameter changed; "
+                                       "ms_with_weight_prep = the same with weight norm + repack of all 56 layers forced per call",
+                               "algorithmic_bytes": fb, "algorithmic_flop": ff,
                                "hbm_roofline_frac": fb / t_fwd / HBM_PEAK,
                                "f32_mfma_frac": ff / t_fwd / F32_MFMA_PEAK,
+                               "x6_mfma_frac": ff / t_fwd / X6_MFMA_PEAK,
                                "samples_per_s": args.batch * args.n_signal / t_fwd}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "v2":
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
@@ -356,7 +399,12 @@ def main():
         tot = red_gen.bytes_reduced + (red_dis.bytes_reduced if red_dis else 0)
         ovl = red_gen.bytes_overlapped + (red_dis.bytes_overlapped if red_dis else 0)
         nst = max(args.warmup + args.steps, 1)
+        exp_ms = sorted(a.elapsed_time(b) for a, b in ddp_exposed) if ddp_exposed else []
         out["ddp"] = {"allreduce_bytes_per_step": tot // nst, "buckets": len(red_gen.buckets), "backend": "nccl (RCCL)",
+                      "exposed_ms": exp_ms[len(exp_ms) // 2] if exp_ms else None,
+                      "exposed_ms_note": "median GPU time between the end of backward and the last bucket's all-reduce on "
+                                         "the compute stream (HIP events around GradReducer.finish() in eager steps)",
+                      "bytes_packed_per_step": (red_gen.bytes_packed + (red_dis.bytes_packed if red_dis else 0)) // nst,
                       "bytes_issued_before_backward_ended_per_step": ovl // nst,
                       "overlap_fraction": ovl / tot if tot else None,
                       "buffer_broadcast_bytes_per_step": bufsync.bytes_sent // nst}

@@ -55,7 +55,6 @@ struct ConvP {
     int Mr;                                    // real output channels (M = Mr * vs there)
     int v_o0;                                  // output index of row j of column n = n * vs + v_o0 + j
     int v_U, v_b0;                             // taps of the virtual gather, offsets b0 - u
-    int skew_ticks, skew_mode;                 // experiment (RH_X6_SKEW_US / RH_X6_SKEW_MODE): start delay of half the workgroups
     long ph_q2ofs[kMaxPhases];                 // first fragment (16-byte units) of each phase in wq
     long x6_wofs;                              // floats between wp and the bf16x6 section of the packed operand
     int nphase;

@@ -170,13 +170,6 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;
     dim3 grid(pl.col_tiles, pl.row_tiles, q.nphase * q.ksplit);
-    {   // experiment: phase skew between the two workgroups of a CU (one-round grids only), see conv_x6_kernel.inc
-        static const int skew_us10 = [] { const char* e = getenv("RH_X6_SKEW_US"); return e ? (int)(atof(e) * 10.0) : 0; }();
-        static const int skew_mode = [] { const char* e = getenv("RH_X6_SKEW_MODE"); return e ? atoi(e) : 0; }();
-        const long wgs = (long)grid.x * grid.y * grid.z;
-        q.skew_ticks = (skew_us10 > 0 && wgs > 256 && wgs <= 512) ? skew_us10 * 10 : 0;      // 100 ticks per microsecond
-        q.skew_mode = skew_mode;
-    }
     if (q.is == 1) rh_x6_dispatch_is1(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     else if (q.is == 2) rh_x6_dispatch_is2(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
     else rh_x6_dispatch_is4(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);

@@ -6,14 +6,21 @@ The reference has no collective call of its own: multi-GPU training is Lightning
 path: clips are independent, so the only exchange is the gradient mean.
 
 * parameters are grouped into ~32 MiB buckets in REVERSE registration order (= the order their
-  gradients become final during backward: discriminator -> decoder -> encoder);
-* a post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its grads
-  are packed into one flat buffer and an asynchronous all-reduce is issued at once (RCCL runs it
-  on its own stream, overlapping the remaining backward kernels);
-* ``finish()`` (called between backward and optimizer.step) waits, averages and scatters back.
-  Buckets that did not complete (parameters without a gradient this step, e.g. the discriminator
-  in the VAE phase) are flushed with whatever gradients exist -- all ranks run the same phase, so
-  the pattern is identical everywhere.
+  gradients become final during backward: discriminator -> decoder -> encoder); every bucket owns ONE
+  persistent flat buffer and every parameter a view into it;
+* **gradients live in the buckets**: the weight-gradient / weight-norm backward kernels of the conv operators write
+  straight into the parameter's view (rave_amd.ops: ``grad_slot``) and hand that view to autograd, which adopts it as
+  ``p.grad`` -- no pack pass before the all-reduce and no copy-back after it (round 2 paid 2 x 126 MB of copies per
+  step).  A gradient produced by anything else (torch ops: Snake alpha, BatchNorm) is copied into its view once by
+  the hook and ``p.grad`` re-bound to the view;
+* a post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete ONE asynchronous all-reduce
+  over its flat buffer is enqueued (RCCL's own stream: it overlaps the remaining backward kernels).  The reduction
+  is ``AVG`` where the backend has it (RCCL), else ``SUM`` + one scale pass (gloo);
+* ``finish()`` (between backward and optimizer.step) waits.  Buckets that did not complete (parameters without a
+  gradient this step) are flushed with the missing views zeroed; their ``p.grad`` stays ``None``;
+* everything is stream-ordered (no host synchronisation): ``begin() ... backward ... finish()`` can be recorded into a
+  hipGraph together with the rest of the step -- RCCL collectives are capturable -- so a data-parallel rank replays
+  the same single graph launch per step as a single-GPU run (rave_amd.model.GraphedTrainingStep(grad_sync=...)).
 
 xGMI is point-to-point (7 links per GPU); a few large messages keep every link busy, hence the
 larger-than-NCCL-default bucket.
@@ -31,10 +38,12 @@ class _Bucket:
         self.params = params
         self.numel = sum(p.numel() for p in params)
         self.flat: Optional[torch.Tensor] = None
+        self.views: List[torch.Tensor] = []
         self.pending = 0
-        self.ready: List[torch.nn.Parameter] = []
+        self.arrived: List[bool] = []
+        self.index = {}
         self.work = None
-        self.sent: List[torch.nn.Parameter] = []
+        self.launched = False
 
 
 class GradReducer:
@@ -60,77 +69,103 @@ class GradReducer:
         self._where = {}
         self._hooks = []
         for b in self.buckets:
-            for p in b.params:
+            p0 = b.params[0]
+            b.flat = torch.zeros(b.numel, dtype=p0.dtype, device=p0.device)
+            o = 0
+            for i, p in enumerate(b.params):
+                if p.dtype != p0.dtype or p.device != p0.device:
+                    raise ValueError("GradReducer: parameters of one reducer must share dtype and device")
+                v = b.flat[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+                b.views.append(v)
+                b.index[p] = i
+                # [view, fresh]: the conv operators' backward writes the gradient into `view` and returns it while
+                # `fresh` (set by begin(), cleared by the first writer of the step) -- rave_amd.ops.grad_slot
+                p._rh_grad_slot = [v, False]
                 self._where[p] = b
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self._avg = backend == "nccl"          # RCCL reduces with ncclAvg; gloo has SUM only
         self.enabled = False
         self.bytes_reduced = 0
         self.bytes_overlapped = 0      # bytes whose all-reduce was issued from a hook, i.e. while backward still ran
+        self.bytes_packed = 0          # bytes that had to be copied into a view (gradients not written in place)
         self._in_finish = False
 
     # ---- lifecycle of one step
     def begin(self) -> None:
-        """Call before backward."""
+        """Call before backward (with the gradients of the step's parameters cleared: ``zero_grad(set_to_none=True)``)."""
         self.enabled = self.world > 1 or self.force
         for b in self.buckets:
             b.pending = len(b.params)
-            b.ready = []
+            b.arrived = [False] * len(b.params)
             b.work = None
-            b.sent = []
+            b.launched = False
+            for p in b.params:
+                p._rh_grad_slot[1] = self.enabled and p.grad is None
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if not self.enabled:
             return
         b = self._where[p]
-        b.ready.append(p)
-        b.pending -= 1
-        if b.pending == 0 and self.overlap:
+        i = b.index[p]
+        v = b.views[i]
+        g = p.grad
+        if g is not None and g.data_ptr() != v.data_ptr():
+            with torch.no_grad():
+                v.copy_(g)             # produced outside the conv operators: one copy, then the view IS the gradient
+            p.grad = v
+            self.bytes_packed += p.numel() * 4
+        if not b.arrived[i]:
+            b.arrived[i] = True
+            b.pending -= 1
+        if b.pending == 0 and self.overlap and not b.launched:
             self._launch(b)
 
     def _launch(self, b: _Bucket) -> None:
-        ps = [p for p in b.ready if p.grad is not None]
-        if not ps:
-            return
-        n = sum(p.numel() for p in ps)
-        if b.flat is None or b.flat.numel() < b.numel or b.flat.device != ps[0].grad.device:
-            b.flat = torch.empty(b.numel, dtype=ps[0].grad.dtype, device=ps[0].grad.device)
-        flat = b.flat[:n]
-        views, o = [], 0
-        for p in ps:
-            views.append(flat[o:o + p.numel()].view_as(p.grad))
-            o += p.numel()
-        torch._foreach_copy_(views, [p.grad for p in ps])
-        b.sent = ps
-        b._views = views
-        b.work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self.bytes_reduced += n * 4
+        missing = [v for v, a in zip(b.views, b.arrived) if not a]
+        if len(missing) == len(b.views):
+            return                     # nothing in this bucket received a gradient this step
+        if missing:
+            with torch.no_grad():
+                torch._foreach_zero_(missing)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
+        b.launched = True
+        self.bytes_reduced += b.numel * 4
         if not self._in_finish:
-            self.bytes_overlapped += n * 4
+            self.bytes_overlapped += b.numel * 4
 
     def finish(self) -> None:
-        """Call after backward, before optimizer.step(): wait for the collectives and write the
-        averaged gradients back."""
+        """Call after backward, before optimizer.step(): flush incomplete buckets, wait for the collectives."""
         if not self.enabled:
             return
         self._in_finish = True
         for b in self.buckets:
-            if b.work is None:
+            if not b.launched:
                 self._launch(b)      # incomplete bucket or overlap disabled
         self._in_finish = False
-        inv = 1.0 / self.world
         for b in self.buckets:
             if b.work is None:
                 continue
             b.work.wait()
-            torch._foreach_mul_(b._views, inv)
-            torch._foreach_copy_([p.grad for p in b.sent], b._views)
+            if not self._avg:
+                with torch.no_grad():
+                    b.flat.mul_(1.0 / self.world)
             b.work = None
+        for b in self.buckets:
+            for p in b.params:
+                p._rh_grad_slot[1] = False
         self.enabled = False
 
     def remove(self) -> None:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for b in self.buckets:
+            for p in b.params:
+                if hasattr(p, "_rh_grad_slot"):
+                    del p._rh_grad_slot
 
 
 class BufferSync:

@@ -96,15 +96,16 @@ class RAVE(nn.Module):
             self._beta_dev.fill_(float(self.beta_factor))
         return self._beta_dev
 
-    def prepare_weights(self, with_discriminator: bool = False):
+    def prepare_weights(self, with_discriminator: bool = False, reuse: bool = False):
         """Refresh weight norm + packed weights of every conv in two launches (see rave_amd/prep.py);
-        pair with release_weights().  training_step does this itself."""
+        pair with release_weights().  training_step does this itself.  ``reuse=True``: inference forwards -- keep the
+        packed operands while no parameter changed (rave_amd.prep.WeightPrep.run)."""
         from .prep import WeightPrep
         if self._prep is None:
             self._prep = (WeightPrep(nn.ModuleList([self.encoder, self.decoder])), WeightPrep(self.discriminator))
-        self._prep[0].run()
+        self._prep[0].run(reuse)
         if with_discriminator:
-            self._prep[1].run()
+            self._prep[1].run(reuse)
 
     def set_phase_flags_eagerly(self) -> None:
         """Read every buffer-derived host flag once outside a capture (so that a following capture finds them cached
@@ -186,9 +187,10 @@ class RAVE(nn.Module):
 
     # ---- rave/model.py:288-424
     def training_step(self, batch, batch_idx, eps: Optional[torch.Tensor] = None, grad_sync=None,
-                      capture_safe: bool = False):
-        """``eps`` injects the reparametrisation noise (parity runs); ``grad_sync(optimizer_index)``
-        is called between backward and optimizer.step (data-parallel gradient averaging).
+                      capture_safe: bool = False, grad_begin=None):
+        """``eps`` injects the reparametrisation noise (parity runs); ``grad_begin(optimizer_index)`` is called right
+        after that optimizer's ``zero_grad()`` and ``grad_sync(optimizer_index)`` between backward and optimizer.step
+        (data-parallel gradient averaging: rave_amd.ddp.GradReducer.begin / finish).
         ``capture_safe``: no host synchronisation inside the step (the reference's ``reg.item()`` test,
         rave/model.py:393, becomes "always add the regulariser" -- identical whenever it is non-zero, i.e. always
         for the variational encoder), so that the step can be recorded into a hipGraph."""
@@ -279,12 +281,16 @@ class RAVE(nn.Module):
 
         if dis_step:
             dis_opt.zero_grad()
+            if grad_begin is not None:
+                grad_begin(1)
             loss_dis.backward()
             if grad_sync is not None:
                 grad_sync(1)
             dis_opt.step()
         else:
             gen_opt.zero_grad()
+            if grad_begin is not None:
+                grad_begin(0)
             loss_gen_value = 0.
             for k, v in loss_gen.items():
                 loss_gen_value += v * self.weights.get(k, 1.)
@@ -294,6 +300,9 @@ class RAVE(nn.Module):
             gen_opt.step()
 
         self.release_weights()
+        if self._prep is not None:       # (fused optimizers do not bump parameter version counters)
+            for pr in self._prep:
+                pr.invalidate()
         self.logged = dict(loss_gen)
         self.logged["loss_dis"] = loss_dis
         return self.logged
@@ -340,8 +349,15 @@ class GraphedTrainingStep:
     (``EuclideanCodebook.inited == 0`` with the quantizer enabled) is refused -- run eager steps until the k-means
     init has happened, then construct / call this class."""
 
-    def __init__(self, model: "RAVE", example_batch: torch.Tensor, inject_eps: bool = False, warmup_iters: int = 3):
+    def __init__(self, model: "RAVE", example_batch: torch.Tensor, inject_eps: bool = False, warmup_iters: int = 3,
+                 grad_begin=None, grad_sync=None, before_step=None):
+        """``grad_begin`` / ``grad_sync``: the data-parallel reducer's begin / finish (rave_amd.ddp.GradReducer), recorded
+        INTO the graph -- the bucket all-reduces are stream-ordered RCCL launches, capturable like any kernel, so a
+        data-parallel rank replays one graph per step exactly like a single-GPU run.  ``before_step``: called at the
+        start of the recorded region (rave_amd.ddp.BufferSync.sync: the per-step buffer broadcast)."""
         self.model = model
+        self.sync_kw = dict(grad_begin=grad_begin, grad_sync=grad_sync)
+        self.before_step = before_step
         self.x = example_batch.detach().clone()
         self.eps = None
         if inject_eps:
@@ -395,7 +411,9 @@ class GraphedTrainingStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(self.warmup_iters):
-                    m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True)
+                    if self.before_step is not None:
+                        self.before_step()
+                    m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True, **self.sync_kw)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             m.load_state_dict(state[0])
@@ -412,7 +430,9 @@ class GraphedTrainingStep:
             m.set_phase_flags_eagerly()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True)
+                if self.before_step is not None:
+                    self.before_step()
+                logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True, **self.sync_kw)
             # the capture itself does not execute anything: parameters are still the restored ones
             self.graphs[key] = (g, logged)
         g, logged = self.graphs[key]

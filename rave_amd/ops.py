@@ -276,11 +276,29 @@ def _pack(d, w3, g, need_bwd, dev, s, prepacked=None):
     return wp_f, wp_b, norms
 
 
-def _wn_bwd(dw, v, g, norms, s):
+def _slot_of(p):
+    """The parameter's gradient slot ([view into a flat all-reduce bucket, fresh flag]) installed by
+    rave_amd.ddp.GradReducer, or None."""
+    return getattr(p, "_rh_grad_slot", None) if p is not None else None
+
+
+def _grad_out(slot, shape, device) -> Tensor:
+    """Where a parameter gradient is written: the parameter's bucket view while the data-parallel reducer has marked it
+    fresh for this step (autograd then adopts the view as ``p.grad``: no pack / copy-back around the all-reduce), else a
+    new tensor.  The first writer of a step takes the view; a parameter used twice accumulates through autograd."""
+    if slot is not None and slot[1] and tuple(slot[0].shape) == tuple(shape) and slot[0].device == device:
+        slot[1] = False
+        # a fresh alias of the view: autograd adopts an incoming gradient (instead of cloning it) only if nothing else
+        # holds the tensor object; the reducer keeps the view itself
+        return slot[0].detach()
+    return torch.empty(tuple(shape), device=device, dtype=torch.float32)
+
+
+def _wn_bwd(dw, v, g, norms, s, slot_v=None, slot_g=None):
     rows = v.shape[0]
     cols = v.numel() // max(rows, 1)
-    dv = torch.empty_like(v)
-    dg = torch.empty_like(g)
+    dv = _grad_out(slot_v, v.shape, v.device)
+    dg = _grad_out(slot_g, g.shape, g.device)
     L.check(L.lib.rh_weight_norm_bwd_f32(L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(norms), rows, cols, L.ptr(dv), L.ptr(dg), s),
             "weight_norm_bwd")
     return dv, dg
@@ -292,6 +310,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, g, bias, alpha, residual, geom: ConvGeom, prepacked=None):
+        ctx.slots = (_slot_of(weight), _slot_of(g), _slot_of(bias))
         x = _chk(x, "x"); weight = _chk(weight, "weight"); g = _chk(g, "weight_g"); bias = _chk(bias, "bias")
         alpha = _chk(alpha, "alpha"); residual = _chk(residual, "residual")
         w3 = weight.reshape(weight.shape[0], weight.shape[1], -1) if weight.dim() == 4 else weight
@@ -330,14 +349,16 @@ class _ConvFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1] or (g is not None and ctx.needs_input_grad[2])
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
         if need_w or need_b:
-            dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
+            slot_w, slot_g, slot_b = ctx.slots
+            # without weight norm the weight gradient IS the parameter gradient: written into its bucket view
+            dw = _grad_out(slot_w if g is None else None, ctx.wshape, dy.device)
             if need_b:
-                db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
+                db = _grad_out(slot_b, (d.c_out,), dy.device)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
             L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
             if g is not None:
-                dw, dg = _wn_bwd(dw, v, g, norms, s)
+                dw, dg = _wn_bwd(dw, v, g, norms, s, slot_w, slot_g)
         if alpha is not None and ctx.needs_input_grad[4]:
             raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.blocks.Snake + conv")
         if ctx.has_res and ctx.needs_input_grad[5]:
@@ -392,6 +413,7 @@ class _ResidualUnitFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w3, g3w, w1, g1w, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom, pre3=None, pre1=None):
+        ctx.slots = (_slot_of(w3), _slot_of(g3w), _slot_of(w1), _slot_of(g1w))
         x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1"); g3w = _chk(g3w, "g3"); g1w = _chk(g1w, "g1")
         alpha0 = _chk(alpha0, "alpha0"); alpha2 = _chk(alpha2, "alpha2")
         b, c, l = x.shape
@@ -428,15 +450,17 @@ class _ResidualUnitFn(torch.autograd.Function):
         nb3 = L.lib.rh_conv1d_workspace_bytes(r3)
         ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
         if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
-            dw1 = torch.empty(ctx.w1shape, device=dev)
+            s3w, s3g, s1w, s1g = ctx.slots
+            dw1 = _grad_out(s1w if g1w is None else None, ctx.w1shape, dev)
             L.check(_wgrad(d1, dy, h, alpha2, dw1, None, ws, nb1, s), "unit k1 wgrad")
             if g1w is not None:
-                dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s)
+                dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s, s1w, s1g)
         if ctx.needs_input_grad[1] or (g3w is not None and ctx.needs_input_grad[2]):
-            dw3 = torch.empty(ctx.w3shape, device=dev)
+            s3w, s3g, s1w, s1g = ctx.slots
+            dw3 = _grad_out(s3w if g3w is None else None, ctx.w3shape, dev)
             L.check(_wgrad(d3, dh, x, alpha0, dw3, None, ws, nb3, s), "unit k3 wgrad")
             if g3w is not None:
-                dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s)
+                dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s, s3w, s3g)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx = act'(x) * dgrad_k3(dh) + dy   (residual gradient fused as `add`)

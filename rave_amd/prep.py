@@ -83,12 +83,15 @@ class WeightPrep:
         autograd's version counters (a replayed hipGraph's optimizer step)."""
         self._packed_versions = None
 
-    def run(self, force: bool = False) -> None:
-        """Refresh the packed weights -- unless no parameter changed since the last refresh (version counters of every
-        weight_v / weight_g: optimizer steps, ``load_state_dict`` and any other in-place write bump them), in which
-        case the persistent buffers are simply re-attached: a no-grad / inference forward pays the weight norm +
-        repack once, not per call.  While a hipGraph is being recorded the kernels always run (the graph must
-        contain them)."""
+    def run(self, reuse: bool = False) -> None:
+        """Refresh the packed weights.  ``reuse=True`` (inference / no-grad forwards): skip the two launches when no
+        parameter changed since the last refresh and re-attach the persistent buffers -- such a forward then pays the
+        weight norm + repack once, not per call.  "Changed" = the version counters of every weight_v / weight_g
+        (``load_state_dict``, in-place tensor ops and foreach optimizers bump them) OR an explicit ``invalidate()``:
+        torch's FUSED optimizers update parameters WITHOUT touching the counters (checked: torch 2.10, Adam(fused=True)),
+        so a training loop must call ``invalidate()`` after its optimizer step -- ``RAVE.training_step`` and
+        ``GraphedTrainingStep`` do.  The default (``reuse=False``) always refreshes, as the reference recomputes every
+        normalised weight on every forward.  While a hipGraph is being recorded the kernels always run."""
         if self.n == 0:
             return
         for m, b in zip(self.mods, self.bufs):
@@ -96,7 +99,7 @@ class WeightPrep:
                 raise RuntimeError("rave_amd.WeightPrep: a parameter was re-allocated; rebuild the WeightPrep")
         capturing = torch.cuda.is_current_stream_capturing()
         ver = self._versions()
-        if force or capturing or ver != getattr(self, "_packed_versions", None):
+        if not reuse or capturing or ver != getattr(self, "_packed_versions", None):
             L.check(L.lib.rh_prep_run_f32(self.items.data_ptr(), self.n, self.total_rows, self.total_blocks, L.stream()),
                     "prep_run")
             # a recorded graph re-runs the repack at every replay, against parameters the replayed optimizer has

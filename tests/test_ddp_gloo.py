@@ -136,3 +136,84 @@ def test_buffer_sync_keeps_ranks_on_rank0_statistics(tmp_path):
     for step in range(3):
         ref(torch.randn(16, 4))
     assert torch.equal(ref.ema, e0)
+
+
+class _SlotLinearFn(torch.autograd.Function):
+    """y = x @ w.T whose backward writes dW where rave_amd.ops._grad_out says -- the protocol the HIP conv operators
+    follow (rave_amd/ops.py): a parameter's bucket view while the reducer marked it fresh, else a new tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from rave_amd.ops import _slot_of
+        ctx.slot = _slot_of(w)
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from rave_amd.ops import _grad_out
+        x, w = ctx.saved_tensors
+        dw = _grad_out(ctx.slot, w.shape, w.device)
+        torch.mm(dy.t(), x, out=dw)
+        return dy @ w, dw
+
+
+def _slot_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rave_amd.ddp import GradReducer
+    torch.manual_seed(0)
+    w1 = nn.Parameter(torch.randn(6, 4))      # gradient written in place by the operator: adopted, never copied
+    w2 = nn.Parameter(torch.randn(3, 6))      # gradient produced by a torch op: copied into its view by the hook
+    w3 = nn.Parameter(torch.randn(6, 4))      # shared weight (two uses): autograd sums the two contributions -> one copy
+    red = GradReducer([w1, w2, w3], bucket_mb=1e-5)
+    torch.manual_seed(5)
+    x = torch.randn(8, 4)
+    xs = x[rank * 4:(rank + 1) * 4]
+    res = []
+    for step in range(3):
+        for p in (w1, w2, w3):
+            p.grad = None
+        red.begin()
+        h = _SlotLinearFn.apply(xs, w1) + _SlotLinearFn.apply(xs, w3) + 0.5 * _SlotLinearFn.apply(xs * 2, w3)
+        (h @ w2.t()).pow(2).mean().backward()
+        red.finish()
+        inside = all(any(b.flat.data_ptr() <= p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4
+                         for b in red.buckets) for p in (w1, w2, w3))
+        res.append((w1.grad.clone(), w2.grad.clone(), w3.grad.clone(), inside))
+    torch.save((res, red.bytes_packed), os.path.join(outdir, f"slot{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradients_live_in_the_buckets_and_in_place_writers_skip_the_pack(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_slot_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    out = [torch.load(os.path.join(str(tmp_path), f"slot{r}.pt"), weights_only=False) for r in range(2)]
+    # reference: full batch, plain autograd
+    torch.manual_seed(0)
+    w1 = torch.randn(6, 4, requires_grad=True)
+    w2 = torch.randn(3, 6, requires_grad=True)
+    w3 = torch.randn(6, 4, requires_grad=True)
+    torch.manual_seed(5)
+    x = torch.randn(8, 4)
+    h = x @ w1.t() + x @ w3.t() + 0.5 * ((x * 2) @ w3.t())
+    (h @ w2.t()).pow(2).mean().backward()
+    for res, packed in out:
+        for g1, g2, g3, inside in res:
+            assert inside                                       # p.grad is a view into a flat all-reduce bucket
+            assert torch.allclose(g1, w1.grad, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(g2, w2.grad, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(g3, w3.grad, rtol=1e-5, atol=1e-6)
+        # w1 (written in place by its operator) was never copied; the torch-op and the shared-weight gradients once per step
+        assert packed == 3 * (w2.numel() + w3.numel()) * 4
+    for (a, _), (b, _) in [(out[0], out[1])]:
+        for ra, rb in zip(a, b):
+            assert all(torch.equal(u, v) for u, v in zip(ra[:3], rb[:3]))

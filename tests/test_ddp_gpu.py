@@ -61,11 +61,17 @@ def _worker(rank, world, port, outdir):
     per = ddp.shard_batch(4, rank, world)
     sl = slice(rank * per, (rank + 1) * per)
     sync.sync()
-    red.begin()
-    m.training_step(x[sl].to(dev), 0, eps=eps[sl].to(dev), grad_sync=lambda idx: red.finish())
+    for it in range(2):                 # the second step starts from adopted bucket views (zero_grad -> None -> views again)
+        m.training_step(x[sl].to(dev), 0, eps=eps[sl].to(dev), grad_begin=lambda idx: red.begin(),
+                        grad_sync=lambda idx: red.finish())
+        if it == 0:                     # compare the FIRST step's gradients (the reference below runs one step)
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
     torch.cuda.synchronize()
-    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    flat_ranges = [(b.flat.data_ptr(), b.flat.data_ptr() + b.flat.numel() * 4) for b in red.buckets]
+    in_bucket = sum(1 for p in gen if p.grad is not None and any(lo <= p.grad.data_ptr() < hi for lo, hi in flat_ranges))
     torch.save(dict(grads=grads, buckets=len(red.buckets), reduced=red.bytes_reduced, overlapped=red.bytes_overlapped,
+                    packed=red.bytes_packed, in_bucket=in_bucket, n_gen=sum(1 for p in gen if p.grad is not None),
                     rf=int(m.receptive_field.sum())), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -97,6 +103,8 @@ def test_two_ranks_average_the_hip_gradients_and_overlap(tmp_path):
         assert o["buckets"] > 1 and o["reduced"] > 0
         assert o["overlapped"] > 0                      # at least one bucket left from a hook, i.e. during backward
         assert o["rf"] == 0                             # rank-0 buffers won
+        assert o["in_bucket"] == o["n_gen"] > 50        # every gradient LIVES in its all-reduce bucket (no copy-back)
+        assert o["packed"] == 0                         # ... and was written there by the backward kernels (no pack pass)
         assert set(o["grads"]) == set(want)
         for k, g in o["grads"].items():
             err = float((g.double() - want[k].double()).norm() / (want[k].double().norm() + 1e-30))
