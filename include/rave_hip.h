@@ -144,6 +144,15 @@ int64_t rh_conv1d_bwd_data_workspace_bytes(const rh_conv1d_desc* d);
  * < 0 = invalid descriptor.  Measurement only (bench.py prices every launch against the peak of the
  * instruction it issues); has_bias / has_add = the optional operands are non-NULL. */
 int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int has_bias, int has_add);
+/* Fused Residual(DilatedUnit) forward -- y = conv_1x1(act(h), w1) + x, h = conv_k_dilated(act(x), w3) -- in ONE launch
+ * (rave/blocks.py:31-45 `Residual`, :83-112 `DilatedUnit`; C = 32 / 64 / 96, stride 1, "same" padding, no biases).
+ * d3 / d1 describe the two convolutions (act / act_slope = the activation in front of each), wp3_fwd / wp1_fwd are
+ * their packed forward operands.  h: receives the intermediate for the backward pass, or NULL (inference: never
+ * written).  Results are bit-identical to rh_conv1d_fwd_f32(d3) followed by rh_conv1d_fwd_f32(d1, residual = x). */
+int rh_residual_unit_fused(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1);   /* 1 = the pair fits the fused launch */
+int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1, const float* x, const float* wp3_fwd,
+                             const float* wp1_fwd, float* h, float* y, rh_stream_t stream);
+
 /* Diagnostics: out8 = {family, row tiles per wave, column tiles per wave, waves along the rows, K slices, input stride of the
  * fragment layout, virtual rows, workgroups} of the launch rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32
  * (which = 1) would issue; zeros behind `family` for the non-bf16x6 families.  Lets the parity tests assert that the

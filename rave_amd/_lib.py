@@ -61,6 +61,8 @@ def _load() -> C.CDLL:
         "rh_conv1d_bwd_data_f32": ([D, P, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_conv1d_kernel_family": ([D, C.c_int, C.c_int, C.c_int], C.c_int),
         "rh_conv1d_bwd_weight_kernel_family": ([D], C.c_int),
+        "rh_residual_unit_fused": ([D, D], C.c_int),
+        "rh_residual_unit_fwd_f32": ([D, D, P, P, P, P, P, P], C.c_int),
         "rh_conv1d_plan_info": ([D, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)], C.c_int),
         "rh_conv1d_fwd_workspace_bytes": ([D], I64),
         "rh_conv1d_bwd_data_workspace_bytes": ([D], I64),

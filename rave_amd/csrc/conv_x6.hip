@@ -137,6 +137,44 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
 
 }  // namespace
 
+// Tile fields of p / LDS bytes / grid for a FORCED tile shape without K split (unit_x6.hip: the fused residual unit needs
+// one row tile per workgroup).  false = the shape does not fit (LDS, 2 GiB descriptors, task slots).
+bool rh_conv_x6_plan_fixed(ConvP& p, int tm, int tn, int wm, size_t* lds, dim3* grid) {
+    if (!x6_enabled() || p.x6_mode != 1 || p.is != 1 || p.inner != 1 || p.nphase != 1) return false;
+    if (((uintptr_t)p.in & 3)) return false;
+    p.vs = 0;
+    p.Mr = p.M;
+    const int wn = 4 / wm;
+    const int BM = 32 * tm * wm, BN = 32 * tn * wn;
+    if (BM != p.Mp) return false;
+    int bnl = BN;
+    if (p.ncols < BN) {
+        bnl = 32;
+        while (bnl < p.ncols) bnl <<= 1;
+    }
+    p.bnl = bnl;
+    p.bnl_shift = __builtin_ctz(bnl);
+    p.nb = BN / bnl;
+    p.tiles_per_b = rh_cdiv(p.ncols, bnl);
+    const int span = (p.ph_maxoff[0] - p.ph_minoff[0]) * p.inner;
+    p.pitch = bnl + span;
+    p.x6_P = p.nb * p.pitch;
+    const int nq = wn * tn == 8 ? 3 : 2;
+    if (2 * p.x6_P > 256 * nq) return false;
+    p.x6_a_units = 6 * BM;
+    p.x6_b_units = 6 * p.x6_P;
+    *lds = (size_t)(2 * p.x6_a_units + 2 * p.x6_b_units) * 16;
+    if (*lds > 160 * 1024) return false;
+    p.ksplit = 1;
+    p.chunks_per_split = p.C >> 4;
+    p.part_stride = (long)p.B * p.Mr * p.out_row;
+    const unsigned long long in_b = 4ull * p.B * p.C * (unsigned long long)p.in_row;
+    const unsigned long long out_b = 4ull * (unsigned long long)p.part_stride;
+    if (!(in_b < 0x7fffffffull && (unsigned long long)p.wq_bytes < 0x7fffffffull && out_b < 0x7fffffffull)) return false;
+    *grid = dim3(rh_cdiv(p.B, p.nb) * p.tiles_per_b, 1, 1);
+    return true;
+}
+
 int64_t rh_conv_x6_workspace(ConvP p) {
     X6Plan pl{};
     if (!plan_x6(p, &pl)) return -1;

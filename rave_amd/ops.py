@@ -200,6 +200,42 @@ def _fwd(d, x, wp, bias, alpha, residual, y, s):
     return rc
 
 
+def _unit_fwd(d3, d1, x, wp3, wp1, h, y, s):
+    """Fused Residual(DilatedUnit) forward (rh_residual_unit_fwd_f32); ``h`` None = inference (never written)."""
+    def run(o_y, o_h):
+        return L.lib.rh_residual_unit_fwd_f32(C.byref(d3), C.byref(d1), L.ptr(x), L.ptr(wp3), L.ptr(wp1), L.ptr(o_h), L.ptr(o_y), s)
+
+    if _PLAN_LOG is not None:
+        _PLAN_LOG.append((2, (d3.c_in, d3.c_out, d3.kernel, d3.stride, d3.dilation, d3.l_in, d3.transposed), (3, d3.c_in // 32, 2, 1, 1, 1, 0, 0)))
+    if _PROFILE is None:
+        rc = run(y, h)
+    else:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = run(y, h)
+        e1.record()
+        f3, b3 = _conv_cost(d3)
+        f1, b1 = _conv_cost(d1)
+        _PROFILE.append(("conv_fwd[x6]", f3 + f1, b3 + b1, e0, e1))
+    if rc == 0 and _SHADOW is not None:
+        # the two-launch path on the exact-f32 kernels, same operands
+        h2, y2 = torch.empty_like(x), torch.empty_like(x)
+        with _ExactF32():
+            nf3 = L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d3))
+            nf1 = L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d1))
+            ws = _ws(max(nf3, nf1, 4), x.device)
+            L.check(L.lib.rh_conv1d_fwd_f32(C.byref(d3), L.ptr(x), L.ptr(wp3), None, None, None, L.ptr(h2), L.ptr(ws), ws.numel() * 4, s),
+                    "shadow unit k3")
+            L.check(L.lib.rh_conv1d_fwd_f32(C.byref(d1), L.ptr(h2), L.ptr(wp1), None, None, L.ptr(x), L.ptr(y2), L.ptr(ws), ws.numel() * 4, s),
+                    "shadow unit k1")
+        key = (d3.c_in, d3.c_out, d3.kernel, d3.stride, d3.dilation, d3.l_in, d3.transposed, d3.batch)
+        _SHADOW.append(("unit", key, _rel(y, y2)))
+        if h is not None:
+            _SHADOW.append(("unit_h", key, _rel(h, h2)))
+    return rc
+
+
 def _dgrad(d, dy, wp, x, alpha, add, dx, s):
     _log_plan(d, 1, False, add is not None)
     ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
@@ -423,10 +459,15 @@ class _ResidualUnitFn(torch.autograd.Function):
         s = L.stream()
         wp3f, wp3b, n3 = _pack(d3, w3, g3w, True, x.device, s, pre3)
         wp1f, wp1b, n1 = _pack(d1, w1, g1w, True, x.device, s, pre1)
-        h = torch.empty_like(x)
         y = torch.empty_like(x)
-        L.check(_fwd(d3, x, wp3f, None, alpha0, None, h, s), "unit k3")
-        L.check(_fwd(d1, h, wp1f, None, alpha2, x, y, s), "unit k1")
+        if alpha0 is None and alpha2 is None and L.lib.rh_residual_unit_fused(C.byref(d3), C.byref(d1)) == 1:
+            # one launch (unit_x6.hip): h stays in registers; it is only written when a backward pass will need it
+            h = torch.empty_like(x) if any(ctx.needs_input_grad[:5]) else None
+            L.check(_unit_fwd(d3, d1, x, wp3f, wp1f, h, y, s), "residual_unit_fwd")
+        else:
+            h = torch.empty_like(x)
+            L.check(_fwd(d3, x, wp3f, None, alpha0, None, h, s), "unit k3")
+            L.check(_fwd(d1, h, wp1f, None, alpha2, x, y, s), "unit k1")
         ctx.save_for_backward(x, h, wp3b, wp1b, alpha0, alpha2, w3 if g3w is not None else None, g3w, n3,
                               w1 if g1w is not None else None, g1w, n1)
         ctx.d3, ctx.d1 = d3, d1

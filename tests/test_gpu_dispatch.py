@@ -115,7 +115,9 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
         kinds[kind] = kinds.get(kind, 0) + 1
         worst_launch = max(worst_launch, err)
         assert err < 2e-6, (kind, key, err)
-    assert kinds == {"fwd": 56, "dgrad": 56, "wgrad": 56}, kinds
+    # the six C = 96 residual units run as ONE fused forward launch each (unit_x6.hip): compared as a pair, y and h
+    assert kinds.get("unit") == 6 and kinds.get("unit_h") == 6, kinds
+    assert kinds["fwd"] + 2 * kinds["unit"] == 56 and kinds["dgrad"] == 56 and kinds["wgrad"] == 56, kinds
     assert worst_launch > 0.0                                 # two different kernels really ran
     o0, g0, _ = _hot_path(dev, 32, sd, xd, ed, cd, RH_CONV_X6=0, RH_WGRAD_X6=0)
     worst = {"out": 0.0, "v": 0.0, "g": 0.0}
@@ -140,9 +142,10 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
     # ---- the batch-32 launches are not the instances the batch-2 tests exercise
     x2, eps2, cots2 = _inputs(dev, 2)
     _, _, plans2 = _hot_path(dev, 2, sd, x2.to(dev), eps2.to(dev), tuple(c.to(dev) for c in cots2), log_plans=True)
-    assert len(plans32) == len(plans2) == 112
-    x6_32 = [p for p in plans32 if p[2][0] == 1]
-    assert len(x6_32) >= 100, len(x6_32)                     # the bf16x6 family carries the generator side
+    count = lambda pl: sum(2 if p[0] == 2 else 1 for p in pl)          # (a fused residual unit stands for two convs)
+    assert count(plans32) == count(plans2) == 112 and len(plans32) == len(plans2)
+    x6_32 = [p for p in plans32 if p[2][0] in (1, 3)]
+    assert count(x6_32) >= 100, len(x6_32)                   # the bf16x6 family carries the generator side
     differ = sum(1 for a, b in zip(plans32, plans2) if a[2][1:5] != b[2][1:5])
     assert differ >= 20, differ                              # other tiles / K splits than at batch 2
 
@@ -179,6 +182,58 @@ def test_full_width_batch8_vs_cpu_oracle(dev):
         assert err < max(tol, 3.0 * ref_err), (k, err, ref_err)
         checked += 1
     assert checked == 112
+
+
+UNIT_CASES = [(32, 96, 4096, 3, 1, False), (32, 96, 4096, 3, 9, False), (3, 96, 300, 3, 3, True), (2, 64, 777, 3, 9, False),
+              (5, 32, 64, 3, 1, False), (1, 96, 37, 5, 2, True), (8, 96, 1024, 7, 1, False)]
+
+
+@pytest.mark.parametrize("case", UNIT_CASES)
+def test_fused_residual_unit_is_bit_identical_to_the_two_launch_path(dev, case):
+    """unit_x6.hip (Residual(DilatedUnit) forward as one launch, h kept in registers) against the two launches it
+    replaces (``RH_UNIT_FUSED=0``): same MFMA sums in the same order per element -> y AND the saved h bit-identical, in
+    training (h written for the backward pass: gradients identical too) and in a no-grad forward (h never written);
+    and against the exact-f32 kernels (<= 2e-6)."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    B, C, L, k, d, causal = case
+    gen = torch.Generator().manual_seed(1000 + C + L)
+    p = (k - 1) * d
+    pad = (p, 0) if causal else (p // 2, p - p // 2)
+    g3 = ConvGeom(dilation=d, pad_left=pad[0], pad_right=pad[1], act=1, slope=0.2)
+    g1 = ConvGeom(act=1, slope=0.2)
+    x = torch.randn(B, C, L, generator=gen).to(dev)
+    w3 = (torch.randn(C, C, k, generator=gen) / (k * C) ** 0.5).to(dev)
+    w1 = (torch.randn(C, C, 1, generator=gen) / C ** 0.5).to(dev)
+    cot = torch.randn(B, C, L, generator=gen).to(dev)
+
+    def run(train, **env):
+        with _Env(**env):
+            if not train:
+                with torch.no_grad():
+                    return (R.residual_unit(x, w3, w1, g3, g1).clone(),)
+            xx, a, b = (t.clone().requires_grad_(True) for t in (x, w3, w1))
+            y = R.residual_unit(xx, a, b, g3, g1)
+            gx, ga, gb = torch.autograd.grad(y, (xx, a, b), cot)
+            torch.cuda.synchronize()
+            return y.detach().clone(), gx.clone(), ga.clone(), gb.clone()
+
+    fused = run(True)
+    split = run(True, RH_UNIT_FUSED=0)
+    for a, b in zip(fused, split):
+        assert torch.equal(a, b)
+    (y_ng,) = run(False)
+    assert torch.equal(y_ng, fused[0])
+    exact = run(True, RH_CONV_X6=0, RH_WGRAD_X6=0)
+    assert 0.0 < rel_l2(fused[0], exact[0]) < 2e-6
+    # the fused launch is the one that ran
+    d3 = R._desc(g3, B, C, C, L, L, k)
+    d1 = R._desc(g1, B, C, C, L, L, 1)
+    import ctypes as Ct
+    from rave_amd import _lib as Lb
+    assert Lb.lib.rh_residual_unit_fused(Ct.byref(d3), Ct.byref(d1)) == 1
+    with _Env(RH_UNIT_FUSED=0):
+        assert Lb.lib.rh_residual_unit_fused(Ct.byref(d3), Ct.byref(d1)) == 0
 
 
 def test_weight_prep_reuse_skips_the_repack_until_a_parameter_changes(dev):
