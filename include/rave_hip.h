@@ -320,6 +320,9 @@ int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_t rows, int
                           int32_t hop, int32_t n_frames, float* frames, rh_stream_t stream);
 int rh_stft_frame_bwd_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
                           int32_t hop, int32_t n_frames, float* dx, rh_stream_t stream);
+/* the same with accumulate != 0: dx += ... (the scales of MultiScaleSTFT, rave/core.py:269-319, add up in place) */
+int rh_stft_frame_bwd_acc_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
+                              int32_t hop, int32_t n_frames, float* dx, int32_t accumulate, rh_stream_t stream);
 
 /* AudioDistanceV1 on one STFT scale (rave/core.py:330-344) from two complex spectrograms (interleaved
  * re,im; n_complex elements each):  sums[0] = sum (|Sx|-|Sy|)^2, sums[1] = sum |Sx|^2,
@@ -336,6 +339,10 @@ int rh_spectral_distance_fwd_f32(const float* sx, const float* sy, int64_t n_com
 int rh_spectral_distance_bwd_f32(const float* sx, const float* sy, const float* sums, const float* grad_out,
                                  int64_t n_complex, float eps, float* dsx, float* dsy, int32_t half_bins,
                                  rh_stream_t stream);
+
+/* AudioDistanceV1.forward's sum over the scales (rave/core.py:336-344): out[0] = sum_s sums[3s]/sums[3s+1] + sums[3s+2]*inv_n[s]
+ * (sums: n_scales x 3 as written by rh_spectral_distance_fwd_f32, inv_n[s] = 1 / n_complex of scale s). */
+int rh_spectral_total_f32(const float* sums, const float* inv_n, int32_t n_scales, float* out, rh_stream_t stream);
 
 #ifdef __cplusplus
 }

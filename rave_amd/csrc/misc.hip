@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void stft_frame_fwd_kernel(const float* __rest
 // dx[r][p] = sum over padded coordinates q that reflect onto p of sum_f window[q - f hop] dframes[r][f][q - f hop]
 __global__ __launch_bounds__(256) void stft_frame_bwd_kernel(const float* __restrict__ dfr, const float* __restrict__ win,
                                                              int t_len, int n, int hop, int n_frames, long total,
-                                                             float* __restrict__ dx) {
+                                                             float* __restrict__ dx, int accumulate) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int p = (int)(e % t_len);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void stft_frame_bwd_kernel(const float* __rest
             s += win[i] * base[(long)f * n + i];
         }
     }
-    dx[e] = s;
+    dx[e] = accumulate ? dx[e] + s : s;      // the scales of a multi-scale distance add up in place (no autograd add passes)
 }
 
 extern "C" int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
@@ -389,15 +389,37 @@ extern "C" int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_
     return rh_check_launch("stft_frame_fwd");
 }
 
-extern "C" int rh_stft_frame_bwd_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len,
-                                     int32_t n_fft, int32_t hop, int32_t n_frames, float* dx, rh_stream_t stream) {
+extern "C" int rh_stft_frame_bwd_acc_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len,
+                                         int32_t n_fft, int32_t hop, int32_t n_frames, float* dx, int32_t accumulate,
+                                         rh_stream_t stream) {
     RH_REQUIRE(dframes && window && dx, RH_ERR_INVALID, "stft_frame_bwd: null pointer");
     RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_bwd: bad geometry");
     const long total = rows * (long)t_len;
     if (total <= 0) return RH_OK;
     hipLaunchKernelGGL(stft_frame_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dframes, window,
-                       t_len, n_fft, hop, n_frames, total, dx);
+                       t_len, n_fft, hop, n_frames, total, dx, accumulate);
     return rh_check_launch("stft_frame_bwd");
+}
+
+extern "C" int rh_stft_frame_bwd_f32(const float* dframes, const float* window, int64_t rows, int32_t t_len,
+                                     int32_t n_fft, int32_t hop, int32_t n_frames, float* dx, rh_stream_t stream) {
+    return rh_stft_frame_bwd_acc_f32(dframes, window, rows, t_len, n_fft, hop, n_frames, dx, 0, stream);
+}
+
+// distance = sum over the scales of sums[s][0] / sums[s][1] + sums[s][2] / n[s]   (rave/core.py:330-344, summed over the
+// scales of MultiScaleSTFT as AudioDistanceV1.forward does): one tiny launch instead of a chain of scalar ATen kernels
+__global__ void spectral_total_kernel(const float* __restrict__ sums, const float* __restrict__ inv_n, int S, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float d = 0.f;
+        for (int s = 0; s < S; ++s) d += sums[3 * s] / sums[3 * s + 1] + sums[3 * s + 2] * inv_n[s];
+        out[0] = d;
+    }
+}
+
+extern "C" int rh_spectral_total_f32(const float* sums, const float* inv_n, int32_t n_scales, float* out, rh_stream_t stream) {
+    RH_REQUIRE(sums && inv_n && out && n_scales > 0, RH_ERR_INVALID, "spectral_total: bad arguments");
+    hipLaunchKernelGGL(spectral_total_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, inv_n, n_scales, out);
+    return rh_check_launch("spectral_total");
 }
 
 extern "C" int64_t rh_spectral_distance_workspace_bytes(void) { return (int64_t)kSpecBlocks * 3 * (int64_t)sizeof(float); }

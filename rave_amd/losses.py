@@ -80,11 +80,9 @@ class AudioDistanceV1(nn.Module):
             from . import ops
             ms = self.multiscale_stft
             xr, yr = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
-            distance = 0.
-            for s in ms.scales:
-                w = getattr(ms, f"window_{s}")
-                distance = distance + ops.stft_distance(ops.stft_frames(xr, w, s, s // 4),
-                                                        ops.stft_frames(yr, w, s, s // 4), float(self.log_epsilon))
+            # all scales in ONE autograd node: the scale sum and the per-signal gradient accumulation happen inside
+            distance = ops.multiscale_stft_distance(xr, yr, [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales,
+                                                    float(self.log_epsilon))
             return {"spectral_distance": distance}
         stfts_x = self.multiscale_stft(x)
         stfts_y = self.multiscale_stft(y)

@@ -871,6 +871,101 @@ def stft_distance(frames_x: Tensor, frames_y: Tensor, eps: float) -> Tensor:
     return _StftDistanceFn.apply(frames_x, frames_y, eps)
 
 
+class _MultiScaleStftDistanceFn(torch.autograd.Function):
+    """AudioDistanceV1 over ALL scales of MultiScaleSTFT as one autograd node (rave/core.py:269-344): per scale the HIP
+    framing kernel, rocFFT R2C and the fused distance kernel; the sum over the scales in one tiny launch; backward: per
+    scale the fused gradient kernel, the C2R adjoint and the framing adjoint ACCUMULATING into one dx / dy buffer.  The
+    per-scale nodes of `stft_distance` cost ~10 scalar ATen launches per scale (divisions, additions and their
+    backwards) and 4 full-size gradient additions per signal -- ~30 % of the launches of a VAE-phase step."""
+
+    @staticmethod
+    def forward(ctx, x, y, eps: float, scales, *windows):
+        x = _chk(x, "x"); y = _chk(y, "y")
+        if x.shape != y.shape or x.dim() != 2:
+            raise RuntimeError("rave_amd multiscale_stft_distance: expects two (rows, T) tensors of equal shape")
+        from . import fft as F
+        rows, t = x.shape
+        s = L.stream()
+        dev = x.device
+        ns = len(scales)
+        sums = torch.empty(ns, 3, device=dev, dtype=torch.float32)
+        nbytes = L.lib.rh_spectral_distance_workspace_bytes()
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        saved = []
+        inv_n = []
+        for i, (n_fft, win) in enumerate(zip(scales, windows)):
+            win = _chk(win, "window")
+            hop = n_fft // 4
+            nf = t // hop + 1
+            specs = []
+            for sig in (x, y):
+                fr = torch.empty(rows, nf, n_fft, device=dev, dtype=torch.float32)
+                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
+                specs.append(F.rfft_last(fr))
+            sx, sy = specs
+            n = sx.numel()
+            L.check(L.lib.rh_spectral_distance_fwd_f32(L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), n, eps,
+                                                       sums[i].data_ptr(), L.ptr(ws), nbytes, s), "spectral_distance_fwd")
+            saved += [sx, sy]
+            inv_n.append(1.0 / n)
+        key = (tuple(inv_n), str(dev))
+        if key not in _INV_N and not torch.cuda.is_current_stream_capturing():
+            _INV_N[key] = torch.tensor(inv_n, dtype=torch.float32, device=dev)
+        inv = _inv_n_cached(tuple(inv_n), dev)
+        out = torch.empty((), device=dev, dtype=torch.float32)
+        L.check(L.lib.rh_spectral_total_f32(L.ptr(sums), L.ptr(inv), ns, L.ptr(out), s), "spectral_total")
+        ctx.save_for_backward(sums, *windows, *saved)
+        ctx.meta = (rows, t, float(eps), tuple(int(v) for v in scales))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, t, eps, scales = ctx.meta
+        ns = len(scales)
+        sums = ctx.saved_tensors[0]
+        windows = ctx.saved_tensors[1:1 + ns]
+        specs = ctx.saved_tensors[1 + ns:]
+        from . import fft as F
+        g = g.contiguous().reshape(1).float()
+        s = L.stream()
+        dev = g.device
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        outs = [torch.empty(rows, t, device=dev, dtype=torch.float32) if nd else None for nd in need]
+        for i, n_fft in enumerate(scales):
+            sx, sy = specs[2 * i], specs[2 * i + 1]
+            hop = n_fft // 4
+            nf = t // hop + 1
+            hx = torch.empty_like(sx) if need[0] else None
+            hy = torch.empty_like(sy) if need[1] else None
+            L.check(L.lib.rh_spectral_distance_bwd_f32(
+                L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), sums[i].data_ptr(), L.ptr(g), sx.numel(), eps,
+                None if hx is None else torch.view_as_real(hx).data_ptr(),
+                None if hy is None else torch.view_as_real(hy).data_ptr(), sx.shape[-1], s), "spectral_distance_bwd")
+            for h, o in ((hx, outs[0]), (hy, outs[1])):
+                if h is None:
+                    continue
+                dfr = F.irfft_last_unnormalized(h, n_fft)
+                L.check(L.lib.rh_stft_frame_bwd_acc_f32(L.ptr(dfr), L.ptr(windows[i]), rows, t, n_fft, hop, nf, L.ptr(o),
+                                                        1 if i > 0 else 0, s), "stft_frame_bwd")
+        return (outs[0], outs[1], None, None) + (None,) * ns
+
+
+_INV_N = {}
+
+
+def _inv_n_cached(key, dev):
+    """1/n per scale on the device, created outside any capture (a hipGraph cannot contain the host-to-device copy)."""
+    k = (key, str(dev))
+    if k not in _INV_N:
+        raise RuntimeError("rave_amd multiscale_stft_distance: first call inside a hipGraph capture (run one eager step first)")
+    return _INV_N[k]
+
+
+def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float) -> Tensor:
+    """sum over the scales of mean((|Sx|-|Sy|)^2)/mean(|Sx|^2) + mean(|log(|Sx|+eps) - log(|Sy|+eps)|) for (rows, T) signals."""
+    return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), *windows)
+
+
 class _AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

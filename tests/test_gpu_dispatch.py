@@ -343,3 +343,28 @@ def test_graphed_step_refuses_uninitialised_rvq(dev):
     step = M.GraphedTrainingStep(m, x)
     with pytest.raises(RuntimeError, match="inited"):
         step(x, 0)
+
+
+def test_multiscale_stft_distance_node_equals_the_per_scale_nodes(dev):
+    """rave_amd.ops.multiscale_stft_distance (all scales of AudioDistanceV1 in one autograd node, gradients of the scales
+    accumulated in place) against the sum of the per-scale nodes it replaces: same kernels -> value equal to rounding of
+    the scalar sum, gradients to 1e-6; and against the torch formulation of rave/core.py:322-344 on the CPU."""
+    from rave_amd import ops as R, losses as LS
+    gen = torch.Generator().manual_seed(4)
+    scales = [2048, 1024, 512, 256, 128]
+    for rows, t in ((3, 16384), (16, 4096)):
+        x = (0.3 * torch.randn(rows, t, generator=gen)).to(dev).requires_grad_(True)
+        y = (0.3 * torch.randn(rows, t, generator=gen)).to(dev).requires_grad_(True)
+        wins = [torch.hann_window(s, device=dev) for s in scales]
+        d1 = R.multiscale_stft_distance(x, y, wins, scales, 1e-7)
+        gx1, gy1 = torch.autograd.grad(d1, (x, y))
+        d2 = 0.
+        for s, w in zip(scales, wins):
+            d2 = d2 + R.stft_distance(R.stft_frames(x, w, s, s // 4), R.stft_frames(y, w, s, s // 4), 1e-7)
+        gx2, gy2 = torch.autograd.grad(d2, (x, y))
+        assert abs(float(d1) - float(d2)) <= 2e-6 * abs(float(d2))
+        assert rel_l2(gx1, gx2) < 1e-6 and rel_l2(gy1, gy2) < 1e-6
+        from functools import partial
+        ref = LS.AudioDistanceV1(partial(LS.MultiScaleSTFT, scales=scales, magnitude=True), 1e-7)
+        d3 = ref(x.detach().cpu().unsqueeze(1), y.detach().cpu().unsqueeze(1))["spectral_distance"]
+        assert abs(float(d1) - float(d3)) <= 2e-5 * abs(float(d3))
