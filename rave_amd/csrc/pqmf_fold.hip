@@ -18,6 +18,7 @@
 // product needs a cross-lane reduction; stores are coalesced along the frame axis.  The direct-form MFMA kernels
 // (pqmf.hip) stay as the bit-level reference for arbitrary `forward_conv.weight` contents; the host side only selects
 // this form when the stored bank equals the closed form to 5e-6 (rave_amd/pqmf.py).
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -139,13 +140,26 @@ __global__ __launch_bounds__(256) void pqmf_fold_k2_kernel(const float* __restri
     }
 }
 
+bool fold_v2() {
+    const char* e = getenv("RH_PQMF_V2");       // read per call (tests): 0 = the first-generation kernels of this file
+    return !(e && atoi(e) == 0);
+}
+
 }  // namespace
+
+// second generation (pqmf_fold2.hip): matrix on the MFMA, sliding-window fold / overlap-add -- bit-identical outputs
+int rh_pqmf_fold_k1v2_launch(const float* in, const float* tab, int rows, int t_len, int n_frames, int o0, float scale, float* out,
+                             hipStream_t stream);
+int rh_pqmf_fold_k2v2_launch(const float* in, const float* tab, int rows, int n_frames, int n_out, int dp, float scale, float* out,
+                             hipStream_t stream);
 
 extern "C" int rh_pqmf_fold_k1_f32(const float* in, const float* tab, int32_t rows, int32_t t_len, int32_t n_frames,
                                    int32_t o0, float scale, float* out, rh_stream_t stream) {
     RH_REQUIRE(rows >= 0 && t_len >= 0 && n_frames >= 0, RH_ERR_INVALID, "pqmf_fold_k1: bad sizes");
     if (rows == 0 || n_frames == 0) return RH_OK;
     RH_REQUIRE(in && tab && out, RH_ERR_INVALID, "pqmf_fold_k1: null pointer");
+    if (fold_v2() && (long)t_len * 4 < 0x7fffffffl && (long)n_frames * 64 < 0x7fffffffl)
+        return rh_pqmf_fold_k1v2_launch(in, tab, rows, t_len, n_frames, o0, scale, out, (hipStream_t)stream);
     hipLaunchKernelGGL(pqmf_fold_k1_kernel, dim3(rh_cdiv(n_frames, kFr1), rows), dim3(256), 0, (hipStream_t)stream, in, tab,
                        out, t_len, n_frames, o0, scale);
     return rh_check_launch("pqmf_fold_k1");
@@ -156,6 +170,8 @@ extern "C" int rh_pqmf_fold_k2_f32(const float* in, const float* tab, int32_t ro
     RH_REQUIRE(rows >= 0 && n_frames >= 0 && n_out >= 0, RH_ERR_INVALID, "pqmf_fold_k2: bad sizes");
     if (rows == 0 || n_out == 0) return RH_OK;
     RH_REQUIRE(in && tab && out, RH_ERR_INVALID, "pqmf_fold_k2: null pointer");
+    if (fold_v2() && (long)n_out * 4 < 0x7fffffffl && (long)n_frames * 64 < 0x7fffffffl)
+        return rh_pqmf_fold_k2v2_launch(in, tab, rows, n_frames, n_out, dp, scale, out, (hipStream_t)stream);
     hipLaunchKernelGGL(pqmf_fold_k2_kernel, dim3(rh_cdiv(n_out, 16 * kFr2), rows), dim3(256), 0, (hipStream_t)stream, in, tab,
                        out, n_frames, n_out, dp, scale);
     return rh_check_launch("pqmf_fold_k2");

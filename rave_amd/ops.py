@@ -897,12 +897,12 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             win = _chk(win, "window")
             hop = n_fft // 4
             nf = t // hop + 1
-            specs = []
-            for sig in (x, y):
-                fr = torch.empty(rows, nf, n_fft, device=dev, dtype=torch.float32)
-                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
-                specs.append(F.rfft_last(fr))
-            sx, sy = specs
+            # both signals in one frames buffer: ONE batched R2C per scale
+            fr = torch.empty(2, rows, nf, n_fft, device=dev, dtype=torch.float32)
+            for k, sig in enumerate((x, y)):
+                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, fr[k].data_ptr(), s), "stft_frame_fwd")
+            spec = F.rfft_last(fr)
+            sx, sy = spec[0], spec[1]
             n = sx.numel()
             L.check(L.lib.rh_spectral_distance_fwd_f32(L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), n, eps,
                                                        sums[i].data_ptr(), L.ptr(ws), nbytes, s), "spectral_distance_fwd")
@@ -935,17 +935,21 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             sx, sy = specs[2 * i], specs[2 * i + 1]
             hop = n_fft // 4
             nf = t // hop + 1
-            hx = torch.empty_like(sx) if need[0] else None
-            hy = torch.empty_like(sy) if need[1] else None
+            both = need[0] and need[1]
+            hh = torch.empty((2,) + tuple(sx.shape), device=dev, dtype=sx.dtype) if both else None
+            hx = hh[0] if both else (torch.empty_like(sx) if need[0] else None)
+            hy = hh[1] if both else (torch.empty_like(sy) if need[1] else None)
             L.check(L.lib.rh_spectral_distance_bwd_f32(
                 L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), sums[i].data_ptr(), L.ptr(g), sx.numel(), eps,
                 None if hx is None else torch.view_as_real(hx).data_ptr(),
                 None if hy is None else torch.view_as_real(hy).data_ptr(), sx.shape[-1], s), "spectral_distance_bwd")
-            for h, o in ((hx, outs[0]), (hy, outs[1])):
-                if h is None:
-                    continue
-                dfr = F.irfft_last_unnormalized(h, n_fft)
-                L.check(L.lib.rh_stft_frame_bwd_acc_f32(L.ptr(dfr), L.ptr(windows[i]), rows, t, n_fft, hop, nf, L.ptr(o),
+            if both:        # ONE batched C2R for both signals
+                dfr = F.irfft_last_unnormalized(hh, n_fft)
+                parts = ((dfr[0], outs[0]), (dfr[1], outs[1]))
+            else:
+                parts = tuple((F.irfft_last_unnormalized(h, n_fft), o) for h, o in ((hx, outs[0]), (hy, outs[1])) if h is not None)
+            for d_fr, o in parts:
+                L.check(L.lib.rh_stft_frame_bwd_acc_f32(d_fr.data_ptr(), L.ptr(windows[i]), rows, t, n_fft, hop, nf, L.ptr(o),
                                                         1 if i > 0 else 0, s), "stft_frame_bwd")
         return (outs[0], outs[1], None, None) + (None,) * ns
 

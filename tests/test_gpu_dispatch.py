@@ -368,3 +368,37 @@ def test_multiscale_stft_distance_node_equals_the_per_scale_nodes(dev):
         ref = LS.AudioDistanceV1(partial(LS.MultiScaleSTFT, scales=scales, magnitude=True), 1e-7)
         d3 = ref(x.detach().cpu().unsqueeze(1), y.detach().cpu().unsqueeze(1))["spectral_distance"]
         assert abs(float(d1) - float(d3)) <= 2e-5 * abs(float(d3))
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("t_len", [16, 48, 2048 + 16, 4096 + 16, 65536])
+def test_pqmf_second_generation_kernels_are_bit_identical_to_the_first(dev, t_len, causal):
+    """pqmf_fold2.hip (matrix on v_mfma_f32_16x16x4_f32, sliding-window fold / overlap-add, staged stores) against
+    pqmf_fold.hip (``RH_PQMF_V2=0``): the same fmaf chains in the same order -> analysis, synthesis and both input
+    gradients bit-identical, ragged tails included."""
+    from rave_amd import cc, pqmf as PQ
+    cc.set_default_padding_mode("causal" if causal else "centered")
+    try:
+        pq = PQ.CachedPQMF(100, 16).to(dev)
+    finally:
+        cc.set_default_padding_mode("centered")
+    gen = torch.Generator().manual_seed(t_len)
+    x = torch.randn(3, 1, t_len, generator=gen).to(dev)
+
+    def run(**env):
+        with _Env(**env):
+            xx = x.clone().requires_grad_(True)
+            y = pq(xx)
+            cy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            (gx,) = torch.autograd.grad(y, xx, cy)
+            yy = y.detach().clone().requires_grad_(True)
+            z = pq.inverse(yy)
+            cz = torch.randn(z.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            (gy,) = torch.autograd.grad(z, yy, cz)
+            torch.cuda.synchronize()
+            return y.detach().clone(), gx.clone(), z.detach().clone(), gy.clone()
+
+    new = run()
+    old = run(RH_PQMF_V2=0)
+    for a, b in zip(new, old):
+        assert a.shape == b.shape and torch.equal(a, b)
