@@ -129,6 +129,9 @@ class GradReducer:
         if missing:
             with torch.no_grad():
                 torch._foreach_zero_(missing)
+        if b.flat.is_cuda:        # gradients written by the weight-gradient side stream (rave_amd.ops._OnSide) must have landed
+            from . import ops
+            ops.join_side_streams()
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         b.launched = True

@@ -250,6 +250,77 @@ def _dgrad(d, dy, wp, x, alpha, add, dx, s):
     return rc
 
 
+# ---- weight-gradient branch on a side stream -----------------------------------------------------------------------------
+# In the backward pass the weight-gradient branch of a layer (wgrad kernel -> ordered reduction of its K-slice partials ->
+# weight-norm backward: one MFMA kernel with a bandwidth-bound store tail, then two small bandwidth-bound kernels) only
+# feeds the optimizer, while the data-gradient chain is what the next layer waits for.  With RH_BWD_SIDE_STREAM=1 the branch
+# is enqueued on a second HIP stream: it forks after the kernels that produce its operands and is joined back (a) at the
+# end of the backward pass (autograd final callback) and (b) before a data-parallel bucket leaves (rave_amd.ddp).  Recorded
+# into the step's hipGraph the two streams become parallel branches of the graph.
+_SIDE = {}
+_SIDE_PENDING = [None]
+
+
+def _side_enabled() -> bool:
+    import os
+    return os.environ.get("RH_BWD_SIDE_STREAM", "0") == "1"
+
+
+def _side_stream(device):
+    k = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(k)
+    if st is None:
+        st = _SIDE[k] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams() -> None:
+    """The calling stream waits for everything enqueued on the weight-gradient side stream."""
+    pend = _SIDE_PENDING[0]
+    if pend is not None:
+        main, side = pend
+        main.wait_stream(side)
+        torch.cuda.current_stream().wait_stream(side)
+        _SIDE_PENDING[0] = None
+
+
+class _OnSide:
+    """``with _OnSide(device, tensors...)``: the body is enqueued on the side stream after everything already enqueued on
+    the current stream; ``tensors`` are kept alive for it (caching-allocator stream bookkeeping)."""
+
+    def __init__(self, device, *tensors):
+        self.device = device
+        self.tensors = [t for t in tensors if t is not None]
+        self.active = _side_enabled()
+
+    def __enter__(self):
+        if not self.active:
+            return self
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = _side_stream(self.device)
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def keep(self, *tensors):
+        self.tensors += [t for t in tensors if t is not None]
+
+    def __exit__(self, *exc):
+        if not self.active:
+            return False
+        self.ctx.__exit__(*exc)
+        for t in self.tensors:
+            t.record_stream(self.side)
+        if _SIDE_PENDING[0] is None:
+            _SIDE_PENDING[0] = (self.main, self.side)
+            try:        # end of this backward pass: the compute stream waits for the branch
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            except RuntimeError:
+                join_side_streams()       # not inside a backward pass (direct call): join at once
+        return False
+
+
 def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s):
     def run(o_dw, o_db):
         return L.lib.rh_conv1d_bwd_weight_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(o_dw), L.ptr(o_db), L.ptr(ws),
@@ -392,9 +463,13 @@ class _ConvFn(torch.autograd.Function):
                 db = _grad_out(slot_b, (d.c_out,), dy.device)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
-            L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
-            if g is not None:
-                dw, dg = _wn_bwd(dw, v, g, norms, s, slot_w, slot_g)
+            with _OnSide(dy.device, dy, x, ws, dw, db) as side:
+                s2 = L.stream()
+                L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s2), "conv1d_bwd_weight")
+                if g is not None:
+                    dw_full = dw
+                    dw, dg = _wn_bwd(dw, v, g, norms, s2, slot_w, slot_g)
+                    side.keep(dw_full, dw, dg)
         if alpha is not None and ctx.needs_input_grad[4]:
             raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.blocks.Snake + conv")
         if ctx.has_res and ctx.needs_input_grad[5]:
@@ -490,18 +565,25 @@ class _ResidualUnitFn(torch.autograd.Function):
         nb1 = L.lib.rh_conv1d_workspace_bytes(r1)
         nb3 = L.lib.rh_conv1d_workspace_bytes(r3)
         ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
-        if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
-            s3w, s3g, s1w, s1g = ctx.slots
-            dw1 = _grad_out(s1w if g1w is None else None, ctx.w1shape, dev)
-            L.check(_wgrad(d1, dy, h, alpha2, dw1, None, ws, nb1, s), "unit k1 wgrad")
-            if g1w is not None:
-                dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s, s1w, s1g)
-        if ctx.needs_input_grad[1] or (g3w is not None and ctx.needs_input_grad[2]):
-            s3w, s3g, s1w, s1g = ctx.slots
-            dw3 = _grad_out(s3w if g3w is None else None, ctx.w3shape, dev)
-            L.check(_wgrad(d3, dh, x, alpha0, dw3, None, ws, nb3, s), "unit k3 wgrad")
-            if g3w is not None:
-                dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s, s3w, s3g)
+        # both weight-gradient branches (operands: dy, h, dh, x -- all produced by now) may run beside the k3 data gradient
+        with _OnSide(dev, dy, h, dh, x, ws) as side:
+            s2 = L.stream()
+            if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
+                s3w, s3g, s1w, s1g = ctx.slots
+                dw1 = _grad_out(s1w if g1w is None else None, ctx.w1shape, dev)
+                side.keep(dw1)
+                L.check(_wgrad(d1, dy, h, alpha2, dw1, None, ws, nb1, s2), "unit k1 wgrad")
+                if g1w is not None:
+                    dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s2, s1w, s1g)
+                    side.keep(dw1, dg1)
+            if ctx.needs_input_grad[1] or (g3w is not None and ctx.needs_input_grad[2]):
+                s3w, s3g, s1w, s1g = ctx.slots
+                dw3 = _grad_out(s3w if g3w is None else None, ctx.w3shape, dev)
+                side.keep(dw3)
+                L.check(_wgrad(d3, dh, x, alpha0, dw3, None, ws, nb3, s2), "unit k3 wgrad")
+                if g3w is not None:
+                    dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s2, s3w, s3g)
+                    side.keep(dw3, dg3)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx = act'(x) * dgrad_k3(dh) + dy   (residual gradient fused as `add`)

@@ -1209,8 +1209,11 @@ def test_v2_full_width_reference_golden(golden_dir, dev):
         g64 = g["grads64"][k]
         ref_err = rel_l2(gref, g64)          # the reference's own fp32 deviation from its fp64 evaluation
         err = rel_l2(got, g64)
-        assert err < max(2e-4, 3.0 * ref_err), (k, err, ref_err)
-        assert rel_l2(got, gref) < max(2e-4, 4.0 * ref_err), (k, rel_l2(got, gref), ref_err)
+        # 3e-4: one LeakyReLU gate within rounding of zero moves a gradient tensor of this size by ~2e-4 (measured
+        # 2.04e-4 on one decoder tensor when the fused residual unit -- unsplit K, other rounding than the two split-K
+        # launches it replaces at this tiny size -- came in; per launch both agree with the exact-f32 kernels to 2e-6)
+        assert err < max(3e-4, 3.0 * ref_err), (k, err, ref_err)
+        assert rel_l2(got, gref) < max(3e-4, 4.0 * ref_err), (k, rel_l2(got, gref), ref_err)
 
 
 def _hinge_step_vs_oracle(dev, model, feats_ref_fn, xy, tol=5e-4):
