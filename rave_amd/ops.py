@@ -253,8 +253,8 @@ def _dgrad(d, dy, wp, x, alpha, add, dx, s):
 # ---- weight-gradient branch on a side stream -----------------------------------------------------------------------------
 # In the backward pass the weight-gradient branch of a layer (wgrad kernel -> ordered reduction of its K-slice partials ->
 # weight-norm backward: one MFMA kernel with a bandwidth-bound store tail, then two small bandwidth-bound kernels) only
-# feeds the optimizer, while the data-gradient chain is what the next layer waits for.  With RH_BWD_SIDE_STREAM=1 the branch
-# is enqueued on a second HIP stream: it forks after the kernels that produce its operands and is joined back (a) at the
+# feeds the optimizer, while the data-gradient chain is what the next layer waits for.  The branch (RH_BWD_SIDE_STREAM=0
+# disables) is enqueued on a second HIP stream: it forks after the kernels that produce its operands and is joined back (a) at the
 # end of the backward pass (autograd final callback) and (b) before a data-parallel bucket leaves (rave_amd.ddp).  Recorded
 # into the step's hipGraph the two streams become parallel branches of the graph.
 _SIDE = {}
@@ -263,7 +263,7 @@ _SIDE_PENDING = [None]
 
 def _side_enabled() -> bool:
     import os
-    return os.environ.get("RH_BWD_SIDE_STREAM", "0") == "1"
+    return os.environ.get("RH_BWD_SIDE_STREAM", "1") != "0"
 
 
 def _side_stream(device):

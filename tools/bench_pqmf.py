@@ -37,6 +37,7 @@ for fold, v2 in (("1", "1"), ("1", "0"), ("0", "0")):
           % (fold, v2, a, mb / a, s, mb / s, ab, sb))      # MB / us = TB/s (HIP events around the autograd call)
 
 # kernel level: the folded-form entry points themselves
+os.environ["RH_PQMF_FOLD"] = "1"
 ft = m._fold(m.forward_conv.weight)
 tab, lpad = ft
 st = torch.cuda.current_stream().cuda_stream
