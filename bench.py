@@ -32,6 +32,10 @@ V2_WEIGHT_BYTES = 126_123_072
 HBM_PEAK = 8.0e12          # B/s   MI355X_MICROARCH.md chip-level parameters
 F32_MFMA_PEAK = 157.3e12   # FLOP/s (f32-input MFMA == f32 vector peak)
 X6_MFMA_PEAK = 2.5e15 / 6  # FLOP/s f32-equivalent of the bf16 matrix cores at 6 MFMAs per product block (conv_x6)
+# what a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on this part with random operands: 20.1 ns per MFMA and
+# SIMD (one wave per SIMD; 17.9 with two) -- the chip is POWER-limited there, the shader clock reads 1.64 GHz instead of
+# 2.4 (tools/probe/mfma_clock.hip, profiles/round3_probe_mfma_clock.txt)
+X6_MFMA_SUSTAINED = 32768 * 1024 / 17.9e-9 / 6
 
 
 def cpu_baseline(n_signal: int, budget_s: float = 25.0):
@@ -123,6 +127,17 @@ def cpu_baseline(n_signal: int, budget_s: float = 25.0):
                       f"torch CPU fp32 oracle (oracle/rave_oracle.py); bounded to ~{budget_s:.0f} s",
             "points": [{"batch": p[1], "threads": p[2], "samples_per_s": p[0]} for p in points],
             "v2_small_forward_loss": small}
+
+
+def _pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC summary (see roofline.traffic_note)."""
+    fam = {"conv_x6_kernel": "conv_x6(fwd+dgrad)", "wgrad_x6_kernel": "wgrad_x6", "wgrad_dma_kernel": "wgrad_f32",
+           "conv_igemm_dma_kernel": "conv_f32(fwd+dgrad)"}.get(kernel_name)
+    try:
+        with open(os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")) as f:
+            return float(json.load(f)[fam]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def main():
@@ -334,10 +349,13 @@ def main():
                                                    else " (forward + data-gradient launches)"),
             "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": fl / (ms * 1e-3) / peak, "frac_vs_exact_f32_peak": fl / (ms * 1e-3) / F32_MFMA_PEAK,
-            "traffic": None,
-            "traffic_note": "HBM bytes per launch are collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                            "passes (tools/pmc_traffic.sh) and kept under profiles/ (round2_pmc_traffic.json), not in "
-                            "this line: the counters cannot be read from inside the timed process",
+            "frac_vs_sustained_mfma_rate": (fl / (ms * 1e-3) / X6_MFMA_SUSTAINED) if peak == X6_MFMA_PEAK else None,
+            "traffic": _pmc_traffic(dom_name),
+            "traffic_note": "HBM bytes per launch (read + write) of this kernel family from rocprofv3 --pmc FETCH_SIZE / "
+                            "WRITE_SIZE passes over this command (separate passes, tools/final_measure.sh), with read / write "
+                            "factors calibrated on tools/probe/fetch_calib in the same call; committed as "
+                            "profiles/round3_pmc_traffic.json and read from there (the counters cannot be collected inside the "
+                            "timed process); null if that file is absent",
             "algorithmic_bytes_per_launch": by / n,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9,
@@ -353,9 +371,13 @@ def main():
                               {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "bound": "hbm",
                                "algorithmic_TBps": v[2] / (v[3] * 1e-3) / 1e12, "peak_TBps": HBM_PEAK / 1e12,
                                "frac_of_hbm_peak": v[2] / (v[3] * 1e-3) / HBM_PEAK}) for k, v in byk.items()}
-        out["roofline"]["mfma_note"] = ("frac is against the NOMINAL rate of the issued MFMA; a loop of nothing but these "
-                                        "MFMAs sustains 0.67-0.80 of it on this part, and VALU work adds to the MFMA time "
-                                        "instead of hiding under it (tools/probe/mfma_valu_overlap.hip, DESIGN.md 4.2)")
+        out["roofline"]["mfma_note"] = ("frac is against the NOMINAL rate of the issued MFMA (2.4 GHz); under a pure "
+                                        "v_mfma_f32_32x32x16_bf16 load with random operands the part is power-limited: the shader "
+                                        "clock reads 1.64 GHz (s_memtime / wall) and one MFMA takes 20.1 ns per SIMD (17.9 with two "
+                                        "waves) = 0.67-0.75 of nominal; up to 2 independent VALU per MFMA gap cost nothing in wall "
+                                        "time, each further one ~1.2 ns (tools/probe/mfma_clock.hip, "
+                                        "profiles/round3_probe_mfma_clock.txt).  frac_vs_sustained_mfma_rate prices the kernel "
+                                        "against that measured rate")
         out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
                                       "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}

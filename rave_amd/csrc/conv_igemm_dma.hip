@@ -341,6 +341,54 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvP p, lon
     p.out[idx] = v;
 }
 
+// the same, four consecutive outputs of one row per thread (16-byte loads / stores): the launch is a pure stream over
+// ksplit + 1 ... ksplit + 3 tensors, and one element per thread kept too few bytes in flight per lane (2-3.5 TB/s)
+__global__ __launch_bounds__(256) void splitk_finalize4_kernel(const ConvP p, long total4) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const long e = 4 * t;
+    const long row = e / p.out_valid;
+    const int oi = (int)(e - row * p.out_valid);
+    const int m = (int)(row % p.M);
+    const long idx = row * p.out_row + oi;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.ksplit; ++z) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p.part + (long)z * p.part_stride + idx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += q[i];
+    }
+    if (p.bias) {
+        const float b = p.bias[m];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += b;
+    }
+    if (p.mul_src) {
+        const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p.mul_src + idx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= rh_act_grad(q[i], p.epi_act, p.epi_slope, al);
+    }
+    if (p.add) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p.add + idx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += q[i];
+    }
+    if (p.out_act == RH_ACT_LEAKY) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.out_slope;
+    }
+    *reinterpret_cast<f32x4*>(p.out + idx) = v;
+}
+
+int finalize_launch(const ConvP& p, hipStream_t stream) {
+    const long total = (long)p.B * p.M * p.out_valid;
+    const bool vec = (p.out_valid & 3) == 0 && (p.out_row & 3) == 0 && (p.part_stride & 3) == 0 &&
+                     (((uintptr_t)p.part | (uintptr_t)p.out | (uintptr_t)p.mul_src | (uintptr_t)p.add) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(splitk_finalize4_kernel, dim3((unsigned)rh_cdiv64(total / 4, 256)), dim3(256), 0, stream, p, total / 4);
+    else hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, p, total);
+    return rh_check_launch("conv_splitk_finalize");
+}
+
 struct Plan { int blocks, total_chunks, ksplit, chunks_per_split; };
 
 Plan plan_split(const ConvP& p, int BM, int col_tiles) {
@@ -459,11 +507,7 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
         else go(conv_igemm_dma_kernel<TM, TN, WM, WN, false, false, true>);
     }
     if (int e = rh_check_launch(what)) return e;
-    if (p.ksplit > 1) {
-        const long total = (long)p.B * p.M * p.out_valid;
-        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, p, total);
-        return rh_check_launch("conv_splitk_finalize");
-    }
+    if (p.ksplit > 1) return finalize_launch(p, stream);
     return RH_OK;
 }
 
@@ -486,11 +530,7 @@ bool rh_conv_dma_eligible(const ConvP& p) {
     return in_b < 0x7fffffffull && w_b < 0x7fffffffull && row_span < 0x7fffffffull;
 }
 
-int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream) {
-    const long total = (long)p.B * p.M * p.out_valid;
-    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, p, total);
-    return rh_check_launch("conv_splitk_finalize");
-}
+int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream) { return finalize_launch(p, stream); }
 
 int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes) {
     fill_sizes(p);

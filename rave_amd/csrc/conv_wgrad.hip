@@ -118,18 +118,25 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_kernel(const WgradP p) {
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               long n, int Z) {
-    // 8 independent running sums keep 8 loads in flight per lane; they are combined in a fixed order,
-    // so the result is still bitwise deterministic.
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    // A workgroup sums 64 consecutive elements; its four waves take the slices z = w, w + 4, w + 8, ... (eight independent
+    // running sums each keep eight loads in flight per lane), then the four wave results are added in a fixed order: the
+    // result is bitwise deterministic, and a small weight tensor with hundreds of K slices (the 96-channel layers:
+    // 27 k elements x 256 slices) spreads over 4 x more workgroups and loads than one thread per element did.
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int z = 0;
-    for (; z + 8 <= Z; z += 8) {
+    if (e < n) {
+        int z = w;
+        for (; z + 28 < Z; z += 32) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += part[(long)(z + u) * n + e];
+            for (int u = 0; u < 8; ++u) s[u] += part[(long)(z + 4 * u) * n + e];
+        }
+        for (; z < Z; z += 4) s[0] += part[(long)z * n + e];
     }
-    for (; z < Z; ++z) s[0] += part[(long)z * n + e];
-    out[e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[w][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (w == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // dbias[m] = sum_{b,h,w} dy * act'(y): grid (M, kBiasSlices) partial sums over interleaved 1024-element segments
@@ -652,7 +659,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     else e = launch_w<2, 2, 2, 2>(p, w, stream);
     if (e) return e;
     if (w.Z > 1) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(nw, 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(nw, 64)), dim3(256), 0, stream,
                            (const float*)ws, dw, nw, w.Z);
         return rh_check_launch("conv1d_bwd_weight_reduce");
     }
@@ -661,7 +668,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
 
 int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what) {
     if (n <= 0) return RH_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 256)), dim3(256), 0, stream, part, out, n, Z);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 64)), dim3(256), 0, stream, part, out, n, Z);
     return rh_check_launch(what);
 }
 

@@ -349,6 +349,30 @@ __global__ __launch_bounds__(256) void stft_frame_fwd_kernel(const float* __rest
     frames[e] = win[i] * x[r * t_len + p];
 }
 
+// four consecutive samples of a frame per thread (16-byte accesses; a quarter of the index divisions): n, hop, t_len
+// multiples of four, 16-byte aligned tensors
+__global__ __launch_bounds__(256) void stft_frame_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ win,
+                                                              int t_len, int n, int hop, int n_frames, unsigned total4,
+                                                              float* __restrict__ frames) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total4) return;
+    const unsigned n4 = (unsigned)n >> 2;
+    const unsigned rf = t / n4;
+    const int i = (int)(t - rf * n4) * 4;
+    const unsigned r = rf / (unsigned)n_frames;
+    const int f = (int)(rf - r * (unsigned)n_frames);
+    const int p0 = f * hop + i - n / 2;
+    const float* __restrict__ xr = x + (long)r * t_len;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(win + i);
+    f32x4 v;
+    if (p0 >= 0 && p0 + 3 < t_len) v = *reinterpret_cast<const f32x4*>(xr + p0);
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = xr[reflect_idx(p0 + k, t_len)];
+    }
+    *reinterpret_cast<f32x4*>(frames + 4l * t) = f32x4{w[0] * v[0], w[1] * v[1], w[2] * v[2], w[3] * v[3]};
+}
+
 // dx[r][p] = sum over padded coordinates q that reflect onto p of sum_f window[q - f hop] dframes[r][f][q - f hop]
 __global__ __launch_bounds__(256) void stft_frame_bwd_kernel(const float* __restrict__ dfr, const float* __restrict__ win,
                                                              int t_len, int n, int hop, int n_frames, long total,
@@ -378,14 +402,77 @@ __global__ __launch_bounds__(256) void stft_frame_bwd_kernel(const float* __rest
     dx[e] = accumulate ? dx[e] + s : s;      // the scales of a multi-scale distance add up in place (no autograd add passes)
 }
 
+// four consecutive samples per thread where no reflected coordinate maps onto them (all but the n/2 samples at either
+// end of a row): the same frames cover all four, 16-byte loads; same additions in the same order as the scalar kernel
+__global__ __launch_bounds__(256) void stft_frame_bwd4_kernel(const float* __restrict__ dfr, const float* __restrict__ win,
+                                                              int t_len, int n, int hop, int n_frames, unsigned total4,
+                                                              float* __restrict__ dx, int accumulate) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total4) return;
+    const unsigned t4 = (unsigned)t_len >> 2;
+    const unsigned r = t / t4;
+    const int p0 = (int)(t - r * t4) * 4;
+    const float* base = dfr + (long)r * n_frames * n;
+    const int half = n / 2;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (p0 > half && p0 + 3 < t_len - 1 - half) {
+        const int q = p0 + half;
+        int f_hi = q / hop;
+        if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+        for (int f = f_hi; f >= 0; --f) {
+            const int i = q - f * hop;
+            if (i >= n) break;
+            const f32x4 w = *reinterpret_cast<const f32x4*>(win + i);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(base + (long)f * n + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += w[k] * d[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = p0 + k;
+            int qs[3];
+            int nq = 0;
+            qs[nq++] = p + half;
+            if (p >= 1 && p <= half) qs[nq++] = half - p;
+            if (p <= t_len - 2 && p >= t_len - 1 - half) qs[nq++] = 2 * (t_len - 1) - p + half;
+            float a = 0.f;
+            for (int j = 0; j < nq; ++j) {
+                const int q = qs[j];
+                int f_hi = q / hop;
+                if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+                for (int f = f_hi; f >= 0; --f) {
+                    const int i = q - f * hop;
+                    if (i >= n) break;
+                    a += win[i] * base[(long)f * n + i];
+                }
+            }
+            s[k] = a;
+        }
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(dx + 4l * t);
+    if (accumulate) {
+        const f32x4 old = *o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = old[k] + s[k];
+    }
+    *o = s;
+}
+
 extern "C" int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_t rows, int32_t t_len, int32_t n_fft,
                                      int32_t hop, int32_t n_frames, float* frames, rh_stream_t stream) {
     RH_REQUIRE(x && window && frames, RH_ERR_INVALID, "stft_frame_fwd: null pointer");
     RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_fwd: bad geometry");
     const long total = rows * (long)n_frames * n_fft;
     if (total <= 0) return RH_OK;
-    hipLaunchKernelGGL(stft_frame_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, window, t_len,
-                       n_fft, hop, n_frames, total, frames);
+    const bool vec = (n_fft & 3) == 0 && (hop & 3) == 0 && (t_len & 3) == 0 && total / 4 < 0xffffffffl &&
+                     (((uintptr_t)x | (uintptr_t)window | (uintptr_t)frames) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(stft_frame_fwd4_kernel, dim3(blocks_for(total / 4)), dim3(256), 0, (hipStream_t)stream, x, window, t_len,
+                           n_fft, hop, n_frames, (unsigned)(total / 4), frames);
+    else
+        hipLaunchKernelGGL(stft_frame_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, window, t_len,
+                           n_fft, hop, n_frames, total, frames);
     return rh_check_launch("stft_frame_fwd");
 }
 
@@ -396,8 +483,14 @@ extern "C" int rh_stft_frame_bwd_acc_f32(const float* dframes, const float* wind
     RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_bwd: bad geometry");
     const long total = rows * (long)t_len;
     if (total <= 0) return RH_OK;
-    hipLaunchKernelGGL(stft_frame_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dframes, window,
-                       t_len, n_fft, hop, n_frames, total, dx, accumulate);
+    const bool vec = (n_fft & 3) == 0 && (hop & 3) == 0 && (t_len & 3) == 0 && total / 4 < 0xffffffffl &&
+                     (((uintptr_t)dframes | (uintptr_t)window | (uintptr_t)dx) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(stft_frame_bwd4_kernel, dim3(blocks_for(total / 4)), dim3(256), 0, (hipStream_t)stream, dframes, window,
+                           t_len, n_fft, hop, n_frames, (unsigned)(total / 4), dx, accumulate);
+    else
+        hipLaunchKernelGGL(stft_frame_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dframes, window,
+                           t_len, n_fft, hop, n_frames, total, dx, accumulate);
     return rh_check_launch("stft_frame_bwd");
 }
 
