@@ -73,7 +73,16 @@ class AudioDistanceV1(nn.Module):
         self.multiscale_stft = multiscale_stft()
         self.log_epsilon = log_epsilon
 
-    def forward(self, x, y):
+    def precompute(self, x):
+        """Start the STFTs of the TARGET ``x`` on the side stream (rave_amd.ops.stft_precompute); pass the result as
+        ``pre=`` to ``forward`` with the same ``x``.  None on the CPU / with the side stream disabled."""
+        if not x.is_cuda:
+            return None
+        from . import ops
+        ms = self.multiscale_stft
+        return ops.stft_precompute(x.reshape(-1, x.shape[-1]), [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales)
+
+    def forward(self, x, y, pre=None):
         if x.is_cuda:
             # fused path: magnitude, both distances and their reductions in one HIP kernel per scale
             # (rh_spectral_distance_*), the STFTs themselves on rocFFT
@@ -82,7 +91,7 @@ class AudioDistanceV1(nn.Module):
             xr, yr = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
             # all scales in ONE autograd node: the scale sum and the per-signal gradient accumulation happen inside
             distance = ops.multiscale_stft_distance(xr, yr, [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales,
-                                                    float(self.log_epsilon))
+                                                    float(self.log_epsilon), pre)
             return {"spectral_distance": distance}
         stfts_x = self.multiscale_stft(x)
         stfts_y = self.multiscale_stft(y)

@@ -206,7 +206,22 @@ class RAVE(nn.Module):
         self.encoder.set_warmed_up(self.warmed_up)
         self.decoder.set_warmed_up(self.warmed_up)
 
-        z, x_multiband = self.encode(x_raw, return_mb=True)
+        x_multiband = _pqmf_encode(self.pqmf, x_raw)                   # (= self.encode(x_raw, return_mb=True), unrolled)
+        rf = (0, 0)
+        if self.valid_signal_crop:                                     # rave/model.py:321-329
+            # the buffer is read on the host (as the reference does); while a hipGraph is being recorded the value
+            # seen by the preceding eager iterations is used (it only changes in validation)
+            if not (batch.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._rf_host = tuple(int(v) for v in self.receptive_field.tolist())
+            rf = getattr(self, "_rf_host", (0, 0))
+        x_mb_loss = valid_signal_crop(x_multiband, rf[0], rf[1]) if rf[0] + rf[1] else x_multiband
+        # the targets of both spectral distances are known now: their STFTs (bandwidth-bound) start on the side stream and
+        # run beside the encoder / decoder forward (matrix-bound); plumbing, same kernels and values
+        pre_mb = pre_fb = None
+        if batch.is_cuda and hasattr(self.audio_distance, "precompute"):
+            pre_mb = self.multiband_audio_distance.precompute(x_mb_loss)
+            pre_fb = self.audio_distance.precompute(x_raw)
+        z = self.encoder(x_multiband)
         z, reg = self.encoder.reparametrize(z, eps)[:2]
 
         y = self.decoder(z)
@@ -214,22 +229,17 @@ class RAVE(nn.Module):
         y_raw = _pqmf_decode(self.pqmf, y, batch_size=batch_size, n_channels=self.n_channels)
         y_raw = y_raw[..., :x_raw.shape[-1]]
         y_multiband = y_multiband[..., :x_multiband.shape[-1]]
-
-        if self.valid_signal_crop:                                     # rave/model.py:321-329
-            # the buffer is read on the host (as the reference does); while a hipGraph is being recorded the value
-            # seen by the preceding eager iterations is used (it only changes in validation)
-            if not (batch.is_cuda and torch.cuda.is_current_stream_capturing()):
-                self._rf_host = tuple(int(v) for v in self.receptive_field.tolist())
-            rf = getattr(self, "_rf_host", (0, 0))
-            if rf[0] + rf[1]:
-                x_multiband = valid_signal_crop(x_multiband, rf[0], rf[1])
-                y_multiband = valid_signal_crop(y_multiband, rf[0], rf[1])
+        if rf[0] + rf[1]:
+            y_multiband = valid_signal_crop(y_multiband, rf[0], rf[1])
+        x_multiband = x_mb_loss
 
         distances = {}
-        multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
+        kw_mb = {"pre": pre_mb} if pre_mb is not None else {}
+        kw_fb = {"pre": pre_fb} if pre_fb is not None else {}
+        multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband, **kw_mb)
         for k, v in multiband_distance.items():
             distances[f"multiband_{k}"] = self.weights["multiband_audio_distance"] * v
-        fullband_distance = self.audio_distance(x_raw, y_raw)
+        fullband_distance = self.audio_distance(x_raw, y_raw, **kw_fb)
         for k, v in fullband_distance.items():
             distances[f"fullband_{k}"] = self.weights["audio_distance"] * v
 

@@ -284,14 +284,35 @@ def join_side_streams() -> None:
         _SIDE_PENDING[0] = None
 
 
+def _note_use(ctx, *params) -> None:
+    """Forward side of the "exactly one pending use" rule of the side stream: a parameter that enters two nodes of one
+    graph gets its two gradients ADDED by autograd on the compute stream -- which must not happen to a tensor the side
+    stream is still writing.  Every differentiable use bumps a counter on the parameter, every backward takes it down."""
+    ps = [p for p in params if p is not None and p.requires_grad]
+    for p in ps:
+        p._rh_pending = getattr(p, "_rh_pending", 0) + 1
+    ctx.rh_params = ps
+
+
+def _single_use(ctx) -> bool:
+    """Backward side: True iff every parameter of this node has exactly this one pending use (then its gradient is adopted
+    by autograd without being read).  Always takes the counters down."""
+    ok = True
+    for p in getattr(ctx, "rh_params", ()):
+        n = getattr(p, "_rh_pending", 1)
+        ok = ok and n == 1
+        p._rh_pending = max(n - 1, 0)
+    return ok
+
+
 class _OnSide:
     """``with _OnSide(device, tensors...)``: the body is enqueued on the side stream after everything already enqueued on
     the current stream; ``tensors`` are kept alive for it (caching-allocator stream bookkeeping)."""
 
-    def __init__(self, device, *tensors):
+    def __init__(self, device, *tensors, allow: bool = True):
         self.device = device
         self.tensors = [t for t in tensors if t is not None]
-        self.active = _side_enabled()
+        self.active = allow and _side_enabled()
 
     def __enter__(self):
         if not self.active:
@@ -418,6 +439,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, g, bias, alpha, residual, geom: ConvGeom, prepacked=None):
         ctx.slots = (_slot_of(weight), _slot_of(g), _slot_of(bias))
+        _note_use(ctx, weight, g, bias)
         x = _chk(x, "x"); weight = _chk(weight, "weight"); g = _chk(g, "weight_g"); bias = _chk(bias, "bias")
         alpha = _chk(alpha, "alpha"); residual = _chk(residual, "residual")
         w3 = weight.reshape(weight.shape[0], weight.shape[1], -1) if weight.dim() == 4 else weight
@@ -445,6 +467,10 @@ class _ConvFn(torch.autograd.Function):
         dy = _chk(dy, "dy")
         s = L.stream()
         dx = dw = dg = db = dres = None
+        # side stream only if (a) nothing autograd may touch on the compute stream is still in use over there: dy is handed
+        # on as the residual's gradient below, and autograd accumulates INTO such tensors in place; (b) the parameters'
+        # gradients are adopted unread (one pending use each)
+        side_ok = _single_use(ctx) and not (ctx.has_res and ctx.needs_input_grad[5])
         if y_act is not None:      # output activation: every gradient below is taken w.r.t. the pre-activation
             gpre = torch.empty_like(dy)
             L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y_act), d.out_act, d.out_slope, dy.numel(), L.ptr(gpre), s),
@@ -463,7 +489,7 @@ class _ConvFn(torch.autograd.Function):
                 db = _grad_out(slot_b, (d.c_out,), dy.device)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
-            with _OnSide(dy.device, dy, x, ws, dw, db) as side:
+            with _OnSide(dy.device, dy, x, ws, dw, db, allow=side_ok) as side:
                 s2 = L.stream()
                 L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s2), "conv1d_bwd_weight")
                 if g is not None:
@@ -525,6 +551,7 @@ class _ResidualUnitFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w3, g3w, w1, g1w, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom, pre3=None, pre1=None):
         ctx.slots = (_slot_of(w3), _slot_of(g3w), _slot_of(w1), _slot_of(g1w))
+        _note_use(ctx, w3, g3w, w1, g1w)
         x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1"); g3w = _chk(g3w, "g3"); g1w = _chk(g1w, "g1")
         alpha0 = _chk(alpha0, "alpha0"); alpha2 = _chk(alpha2, "alpha2")
         b, c, l = x.shape
@@ -566,7 +593,8 @@ class _ResidualUnitFn(torch.autograd.Function):
         nb3 = L.lib.rh_conv1d_workspace_bytes(r3)
         ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
         # both weight-gradient branches (operands: dy, h, dh, x -- all produced by now) may run beside the k3 data gradient
-        with _OnSide(dev, dy, h, dh, x, ws) as side:
+        # (dy is only read here -- the residual gradient is added inside the k3 data-gradient kernel -- and dx is a new tensor)
+        with _OnSide(dev, dy, h, dh, x, ws, allow=_single_use(ctx)) as side:
             s2 = L.stream()
             if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
                 s3w, s3g, s1w, s1g = ctx.slots
@@ -953,6 +981,39 @@ def stft_distance(frames_x: Tensor, frames_y: Tensor, eps: float) -> Tensor:
     return _StftDistanceFn.apply(frames_x, frames_y, eps)
 
 
+class StftPre:
+    """Spectra of the TARGET signal of a multi-scale spectral distance, computed ahead of time on the side stream
+    (``stft_precompute``): the target (the input audio / its PQMF bands) is known at the start of a training step, so its
+    framing + FFT passes (bandwidth-bound) can run beside the encoder / decoder forward (matrix-bound)."""
+
+    def __init__(self, specs, shape, scales, stream):
+        self.specs, self.shape, self.scales, self.stream = specs, tuple(shape), tuple(scales), stream
+
+
+def stft_precompute(x: Tensor, windows, scales):
+    """Complex STFTs (rows, frames, bins) of ``x`` (rows, T) for every scale, enqueued on the side stream after everything
+    already enqueued on the current one; None when the side stream is disabled (RH_BWD_SIDE_STREAM=0)."""
+    if not (x.is_cuda and _side_enabled()):
+        return None
+    from . import fft as F
+    xd = _chk(x.detach(), "x")
+    rows, t = xd.shape
+    main = torch.cuda.current_stream(xd.device)
+    side = _side_stream(xd.device)
+    side.wait_stream(main)
+    specs = []
+    with torch.cuda.stream(side):
+        s = L.stream()
+        for n_fft, win in zip(scales, windows):
+            hop = n_fft // 4
+            nf = t // hop + 1
+            fr = torch.empty(rows, nf, n_fft, device=xd.device, dtype=torch.float32)
+            L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(xd), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
+            specs.append(F.rfft_last(fr, lane=1))
+    xd.record_stream(side)
+    return StftPre(specs, xd.shape, scales, side)
+
+
 class _MultiScaleStftDistanceFn(torch.autograd.Function):
     """AudioDistanceV1 over ALL scales of MultiScaleSTFT as one autograd node (rave/core.py:269-344): per scale the HIP
     framing kernel, rocFFT R2C and the fused distance kernel; the sum over the scales in one tiny launch; backward: per
@@ -961,8 +1022,10 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
     backwards) and 4 full-size gradient additions per signal -- ~30 % of the launches of a VAE-phase step."""
 
     @staticmethod
-    def forward(ctx, x, y, eps: float, scales, *windows):
+    def forward(ctx, x, y, eps: float, scales, pre, *windows):
         x = _chk(x, "x"); y = _chk(y, "y")
+        if pre is not None and (pre.shape != tuple(x.shape) or pre.scales != tuple(scales)):
+            pre = None
         if x.shape != y.shape or x.dim() != 2:
             raise RuntimeError("rave_amd multiscale_stft_distance: expects two (rows, T) tensors of equal shape")
         from . import fft as F
@@ -979,12 +1042,22 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             win = _chk(win, "window")
             hop = n_fft // 4
             nf = t // hop + 1
-            # both signals in one frames buffer: ONE batched R2C per scale
-            fr = torch.empty(2, rows, nf, n_fft, device=dev, dtype=torch.float32)
-            for k, sig in enumerate((x, y)):
-                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, fr[k].data_ptr(), s), "stft_frame_fwd")
-            spec = F.rfft_last(fr)
-            sx, sy = spec[0], spec[1]
+            if pre is None:
+                # both signals in one frames buffer: ONE batched R2C per scale
+                fr = torch.empty(2, rows, nf, n_fft, device=dev, dtype=torch.float32)
+                for k, sig in enumerate((x, y)):
+                    L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, fr[k].data_ptr(), s), "stft_frame_fwd")
+                spec = F.rfft_last(fr)
+                sx, sy = spec[0], spec[1]
+            else:
+                # the target's spectra were computed ahead on the side stream (StftPre): only y here; join before the first use
+                fr = torch.empty(rows, nf, n_fft, device=dev, dtype=torch.float32)
+                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(y), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
+                sy = F.rfft_last(fr)
+                sx = pre.specs[i]
+                if i == 0:
+                    torch.cuda.current_stream(dev).wait_stream(pre.stream)
+                sx.record_stream(torch.cuda.current_stream(dev))
             n = sx.numel()
             L.check(L.lib.rh_spectral_distance_fwd_f32(L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), n, eps,
                                                        sums[i].data_ptr(), L.ptr(ws), nbytes, s), "spectral_distance_fwd")
@@ -1033,7 +1106,7 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             for d_fr, o in parts:
                 L.check(L.lib.rh_stft_frame_bwd_acc_f32(d_fr.data_ptr(), L.ptr(windows[i]), rows, t, n_fft, hop, nf, L.ptr(o),
                                                         1 if i > 0 else 0, s), "stft_frame_bwd")
-        return (outs[0], outs[1], None, None) + (None,) * ns
+        return (outs[0], outs[1], None, None, None) + (None,) * ns
 
 
 _INV_N = {}
@@ -1047,9 +1120,10 @@ def _inv_n_cached(key, dev):
     return _INV_N[k]
 
 
-def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float) -> Tensor:
-    """sum over the scales of mean((|Sx|-|Sy|)^2)/mean(|Sx|^2) + mean(|log(|Sx|+eps) - log(|Sy|+eps)|) for (rows, T) signals."""
-    return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), *windows)
+def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float, pre=None) -> Tensor:
+    """sum over the scales of mean((|Sx|-|Sy|)^2)/mean(|Sx|^2) + mean(|log(|Sx|+eps) - log(|Sy|+eps)|) for (rows, T) signals.
+    ``pre``: ``stft_precompute(x, ...)`` of the same x (its spectra, already under way on the side stream)."""
+    return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), pre, *windows)
 
 
 class _AvgPool2Fn(torch.autograd.Function):

@@ -1,32 +1,56 @@
-# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/r2/
+# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/r3/ (copied into profiles/round3_*)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r2; mkdir -p $O
-timeout 400 python bench.py --steps 20 --warmup 5 < /dev/null > $O/bench_n1.log 2>&1
-timeout 200 python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_n1_eager.log 2>&1
-timeout 300 python bench.py --phase gan --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_gan.log 2>&1
-timeout 300 python bench.py --phase gan --skip-dead-grads --steps 8 --warmup 4 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_gan_skip.log 2>&1
-timeout 300 python bench.py --config discrete --phase gan --batch 32 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_discrete.log 2>&1
-timeout 300 python bench.py --config v3 --phase gan --batch 16 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_v3.log 2>&1
-RAVE_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_dist1.log 2>&1
-timeout 200 python tools/bench_layers.py < /dev/null > $O/layers.log 2>&1
-NIT=10 timeout 200 python tools/check_x6.py < /dev/null > $O/check_x6.log 2>&1
-timeout 100 python tools/bench_pqmf.py < /dev/null > $O/pqmf.log 2>&1
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/prof.log 2>&1 < /dev/null)
-f=$(find $O/prof -name "*.db" | head -1)
-[ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32.md 2>&1
-rm -rf $O/prof
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/profg -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/$O/profg.log 2>&1 < /dev/null)
-f=$(find $O/profg -name "*.db" | head -1)
-[ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32_graph.md 2>&1
-rm -rf $O/profg
-for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1 < /dev/null)
-  python tools/pmc_summary.py $(find $O/pmc_$c -name "*.db" | head -1) > $O/pmc_$c.txt 2>&1
-done
-python tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) $O/pmc_traffic.json > /dev/null 2>&1
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-for w in v2 encodec descript; do N=32; [ $w = v2 ] && N=64; WHICH=$w N=$N timeout 300 python tools/bench_disc2d.py < /dev/null > $O/disc_$w.log 2>&1; done
-for f in bench_n1 bench_n1_eager bench_gan bench_gan_skip bench_discrete bench_v3 bench_dist1; do echo "== $f"; grep "^{" $O/$f.log | tail -1 | cut -c1-330; done
-tail -2 $O/layers.log; tail -1 $O/check_x6.log; grep fold $O/pqmf.log; head -8 $O/kernel_stats_step_b32.md; tail -1 $O/kernel_stats_step_b32.md; tail -1 $O/kernel_stats_step_b32_graph.md
-grep "TOTAL\|fwd+bwd" $O/disc_v2.log $O/disc_encodec.log $O/disc_descript.log
+O=gpurun_out/r3; mkdir -p $O
+PARTS=${PARTS:-all}
+has() { [ "$PARTS" = all ] || echo " $PARTS " | grep -q " $1 "; }
+if has probes; then
+  timeout 120 tools/probe/_var/mfma_clock > $O/probe_mfma_clock.txt 2>&1
+  timeout 60 tools/probe/_var/tr_read > $O/probe_tr_read.txt 2>&1
+fi
+if has bench; then
+  timeout 400 python bench.py --steps 20 --warmup 5 < /dev/null > $O/bench_n1.log 2>&1
+  timeout 200 python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_n1_eager.log 2>&1
+  RAVE_FORCE_DIST=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_dist1.log 2>&1
+fi
+if has others; then
+  timeout 300 python bench.py --phase gan --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_gan.log 2>&1
+  timeout 300 python bench.py --phase gan --skip-dead-grads --steps 8 --warmup 4 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_gan_skip.log 2>&1
+  timeout 300 python bench.py --config discrete --phase gan --batch 32 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_discrete.log 2>&1
+  timeout 300 python bench.py --config v3 --phase gan --batch 16 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_v3.log 2>&1
+fi
+if has layers; then
+  timeout 200 python tools/bench_layers.py < /dev/null > $O/layers.log 2>&1
+  NIT=10 timeout 200 python tools/check_x6.py < /dev/null > $O/check_x6.log 2>&1
+  timeout 100 python tools/bench_pqmf.py < /dev/null > $O/pqmf.log 2>&1
+fi
+if has prof; then
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/prof.log 2>&1 < /dev/null)
+  f=$(find $O/prof -name "*.db" | head -1)
+  [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32.md 2>&1
+  rm -rf $O/prof
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/profg -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/$O/profg.log 2>&1 < /dev/null)
+  f=$(find $O/profg -name "*.db" | head -1)
+  [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32_graph.md 2>&1
+  rm -rf $O/profg
+fi
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1 < /dev/null)
+    python tools/pmc_summary.py $(find $O/pmc_$c -name "*.db" | head -1) > $O/pmc_$c.txt 2>&1
+    (cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/cal_$c -o p -- $GRAFT_REPO_ROOT/tools/probe/_var/fetch_calib > $GRAFT_REPO_ROOT/$O/cal_$c.log 2>&1 < /dev/null)
+    python tools/pmc_summary.py $(find $O/cal_$c -name "*.db" | head -1) > $O/pmc_calib_$c.txt 2>&1
+  done
+  python tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) $O/pmc_traffic.json \
+         $(find $O/cal_FETCH_SIZE -name "*.db" | head -1) $(find $O/cal_WRITE_SIZE -name "*.db" | head -1) > $O/pmc_traffic.log 2>&1
+  rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/cal_FETCH_SIZE $O/cal_WRITE_SIZE
+fi
+if has disc; then
+  for w in v2 encodec descript; do N=32; [ $w = v2 ] && N=64; WHICH=$w N=$N timeout 300 python tools/bench_disc2d.py < /dev/null > $O/disc_$w.log 2>&1; done
+fi
+for f in bench_n1 bench_n1_eager bench_dist1 bench_gan bench_gan_skip bench_discrete bench_v3; do [ -f $O/$f.log ] && { echo "== $f"; grep "^{" $O/$f.log | tail -1 | cut -c1-330; }; done
+[ -f $O/layers.log ] && tail -2 $O/layers.log; [ -f $O/check_x6.log ] && tail -1 $O/check_x6.log; [ -f $O/pqmf.log ] && grep "kernel level\|module" $O/pqmf.log
+[ -f $O/kernel_stats_step_b32_graph.md ] && { head -12 $O/kernel_stats_step_b32_graph.md; tail -1 $O/kernel_stats_step_b32_graph.md; }
+[ -f $O/pmc_traffic.log ] && cat $O/pmc_traffic.log | head -80
+[ -f $O/disc_v2.log ] && grep "TOTAL\|fwd+bwd" $O/disc_v2.log $O/disc_encodec.log $O/disc_descript.log
+true
