@@ -319,10 +319,18 @@ def main():
         # ---- per-launch HIP-event timing of the conv kernels over instrumented replays of the step.  EVERY rank runs
         # these steps (they contain the gradient all-reduce); rank 0 reports.
         reps = 2
+        # (kernels are timed in ISOLATION: the weight-gradient / STFT side stream -- which overlaps launches in the timed
+        # region above -- is switched off for these instrumented steps, so that an event pair brackets one kernel alone)
+        side_env = os.environ.get("RH_BWD_SIDE_STREAM")
+        os.environ["RH_BWD_SIDE_STREAM"] = "0"
         ops.profile_begin()
         for i in range(reps):
             step(args.warmup + args.steps + i, eager=True)     # per-launch events need the eager step
         rec = ops.profile_end()
+        if side_env is None:
+            os.environ.pop("RH_BWD_SIDE_STREAM", None)
+        else:
+            os.environ["RH_BWD_SIDE_STREAM"] = side_env
         fence()
     if rank == 0 and rec is not None:
         agg = {}
@@ -359,6 +367,9 @@ def main():
             "algorithmic_bytes_per_launch": by / n,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9,
+            "timing_note": "per-launch HIP events in eager replays of the step with the side stream off (one kernel at a time); "
+                           "matches profiles/round3_kernel_stats_step_b32.md (rocprofv3 of `bench.py --no-graph` with "
+                           "RH_BWD_SIDE_STREAM=0); the timed region itself overlaps the weight-gradient branch on a second stream",
             "note": "f32 in / f32 accumulate everywhere; peak = that of the instruction the kernel issues (conv_x6_kernel: "
                     "every f32 split exactly into 3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block -> 2.5 PF / 6 = "
                     "417 TFLOP/s f32-equivalent; f32-input MFMA kernels: 157.3); HIP events on the launch stream around "

@@ -291,6 +291,8 @@ def _note_use(ctx, *params) -> None:
     ps = [p for p in params if p is not None and p.requires_grad]
     for p in ps:
         p._rh_pending = getattr(p, "_rh_pending", 0) + 1
+        if p._rh_pending > 1:
+            p._rh_shared = True          # stays set until every pending use has been taken down
     ctx.rh_params = ps
 
 
@@ -300,8 +302,10 @@ def _single_use(ctx) -> bool:
     ok = True
     for p in getattr(ctx, "rh_params", ()):
         n = getattr(p, "_rh_pending", 1)
-        ok = ok and n == 1
+        ok = ok and n == 1 and not getattr(p, "_rh_shared", False)
         p._rh_pending = max(n - 1, 0)
+        if p._rh_pending == 0:
+            p._rh_shared = False
     return ok
 
 
@@ -489,7 +493,7 @@ class _ConvFn(torch.autograd.Function):
                 db = _grad_out(slot_b, (d.c_out,), dy.device)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
-            with _OnSide(dy.device, dy, x, ws, dw, db, allow=side_ok) as side:
+            with _OnSide(dy.device, dy, x, ws, dw, db, v, g, norms, alpha, allow=side_ok) as side:
                 s2 = L.stream()
                 L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s2), "conv1d_bwd_weight")
                 if g is not None:
@@ -594,7 +598,7 @@ class _ResidualUnitFn(torch.autograd.Function):
         ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
         # both weight-gradient branches (operands: dy, h, dh, x -- all produced by now) may run beside the k3 data gradient
         # (dy is only read here -- the residual gradient is added inside the k3 data-gradient kernel -- and dx is a new tensor)
-        with _OnSide(dev, dy, h, dh, x, ws, allow=_single_use(ctx)) as side:
+        with _OnSide(dev, dy, h, dh, x, ws, v3, g3w, n3, v1, g1w, n1, alpha0, alpha2, allow=_single_use(ctx)) as side:
             s2 = L.stream()
             if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
                 s3w, s3g, s1w, s1g = ctx.slots
@@ -993,7 +997,8 @@ class StftPre:
 def stft_precompute(x: Tensor, windows, scales):
     """Complex STFTs (rows, frames, bins) of ``x`` (rows, T) for every scale, enqueued on the side stream after everything
     already enqueued on the current one; None when the side stream is disabled (RH_BWD_SIDE_STREAM=0)."""
-    if not (x.is_cuda and _side_enabled()):
+    import os
+    if not (x.is_cuda and _side_enabled()) or os.environ.get("RH_STFT_PRECOMPUTE", "1") == "0":
         return None
     from . import fft as F
     xd = _chk(x.detach(), "x")

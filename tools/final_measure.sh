@@ -25,7 +25,7 @@ if has layers; then
   timeout 100 python tools/bench_pqmf.py < /dev/null > $O/pqmf.log 2>&1
 fi
 if has prof; then
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/prof.log 2>&1 < /dev/null)
+  (cd /tmp && RH_BWD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/prof.log 2>&1 < /dev/null)
   f=$(find $O/prof -name "*.db" | head -1)
   [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32.md 2>&1
   rm -rf $O/prof
@@ -36,7 +36,7 @@ if has prof; then
 fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1 < /dev/null)
+    (cd /tmp && RH_BWD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1 < /dev/null)
     python tools/pmc_summary.py $(find $O/pmc_$c -name "*.db" | head -1) > $O/pmc_$c.txt 2>&1
     (cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/cal_$c -o p -- $GRAFT_REPO_ROOT/tools/probe/_var/fetch_calib > $GRAFT_REPO_ROOT/$O/cal_$c.log 2>&1 < /dev/null)
     python tools/pmc_summary.py $(find $O/cal_$c -name "*.db" | head -1) > $O/pmc_calib_$c.txt 2>&1
