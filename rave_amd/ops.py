@@ -266,8 +266,11 @@ def _side_enabled() -> bool:
     return os.environ.get("RH_BWD_SIDE_STREAM", "1") != "0"
 
 
-def _side_stream(device):
-    k = device.index if device.index is not None else torch.cuda.current_device()
+def _side_stream(device, lane: int = 0):
+    """lane 0: the weight-gradient branch of the backward pass; lane 1: the spectral-loss target STFTs of the forward
+    pass.  Two streams: re-forking a capture stream after it has been joined once mid-capture gave graphs whose replays
+    raced (measured: tools/debug/precompute_identity.py); with one fork / join pattern per stream they do not."""
+    k = (device.index if device.index is not None else torch.cuda.current_device(), lane)
     st = _SIDE.get(k)
     if st is None:
         st = _SIDE[k] = torch.cuda.Stream(device=device)
@@ -316,7 +319,8 @@ class _OnSide:
     def __init__(self, device, *tensors, allow: bool = True):
         self.device = device
         self.tensors = [t for t in tensors if t is not None]
-        self.active = allow and _side_enabled()
+        import os
+        self.active = allow and _side_enabled() and os.environ.get("RH_WGRAD_SIDE", "1") != "0"
 
     def __enter__(self):
         if not self.active:
@@ -998,13 +1002,18 @@ def stft_precompute(x: Tensor, windows, scales):
     """Complex STFTs (rows, frames, bins) of ``x`` (rows, T) for every scale, enqueued on the side stream after everything
     already enqueued on the current one; None when the side stream is disabled (RH_BWD_SIDE_STREAM=0)."""
     import os
-    if not (x.is_cuda and _side_enabled()) or os.environ.get("RH_STFT_PRECOMPUTE", "1") == "0":
+    # OPT-IN (RH_STFT_PRECOMPUTE=1), off by default: eager steps and graph replays are bit-identical with it alone, and with
+    # the weight-gradient side branch alone, but hipGraph replays of a step that contains BOTH forks come out
+    # nondeterministic in the last bits (tools/debug/precompute_identity.py: 3 of 4 captures, also with two separate side
+    # streams; an immediate join after the fork -- same memory pattern, no concurrency -- is clean).  Unresolved; the
+    # backward branch is the one kept (it is worth more).
+    if not (x.is_cuda and _side_enabled()) or os.environ.get("RH_STFT_PRECOMPUTE", "0") != "1":
         return None
     from . import fft as F
     xd = _chk(x.detach(), "x")
     rows, t = xd.shape
     main = torch.cuda.current_stream(xd.device)
-    side = _side_stream(xd.device)
+    side = _side_stream(xd.device, lane=1)
     side.wait_stream(main)
     specs = []
     with torch.cuda.stream(side):
@@ -1016,6 +1025,8 @@ def stft_precompute(x: Tensor, windows, scales):
             L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(xd), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
             specs.append(F.rfft_last(fr, lane=1))
     xd.record_stream(side)
+    if os.environ.get("RH_STFT_PRE_JOIN", "0") == "1":      # debugging aid: no concurrency, same memory pattern
+        main.wait_stream(side)
     return StftPre(specs, xd.shape, scales, side)
 
 
