@@ -344,6 +344,21 @@ int rh_spectral_distance_bwd_f32(const float* sx, const float* sy, const float* 
  * (sums: n_scales x 3 as written by rh_spectral_distance_fwd_f32, inv_n[s] = 1 / n_complex of scale s). */
 int rh_spectral_total_f32(const float* sums, const float* inv_n, int32_t n_scales, float* out, rh_stream_t stream);
 
+/* AudioDistanceV1 on one STFT scale (rave/core.py:269-344: Spectrogram(n_fft, hop = n_fft / 4, center, reflect) -> |.| ->
+ * relative L2 + L1 of logs) with the transform INSIDE the kernel: x, y (rows, t_len) f32 waveforms, window (n_fft, the
+ * normalised window the reference multiplies the frames by), twiddle (n_fft complex: e^{-2 pi i k / n_fft}, interleaved).
+ * n_fft in {128, 256, 512, 1024, 2048}, hop = n_fft / 4, t_len > n_fft / 2 (rh_stft_loss_supported).  Same `sums` as
+ * rh_spectral_distance_fwd_f32 (n_complex = rows * (t_len / hop + 1) * (n_fft / 2 + 1)); the backward recomputes the
+ * spectra, and writes (accumulate = 0) or adds (!= 0) d distance / d x and / d y (either may be NULL) times grad_out[0]. */
+int rh_stft_loss_supported(int32_t n_fft, int32_t hop, int32_t t_len, int64_t rows);
+int64_t rh_stft_loss_workspace_bytes(int32_t n_fft, int32_t t_len, int64_t rows);
+int rh_stft_loss_fwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,
+                         int32_t t_len, int32_t n_fft, float eps, float* sums, void* workspace, int64_t workspace_bytes,
+                         rh_stream_t stream);
+int rh_stft_loss_bwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,
+                         int32_t t_len, int32_t n_fft, float eps, const float* sums, const float* grad_out, float* dx,
+                         float* dy, int32_t accumulate, rh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1050,6 +1050,28 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
         dev = x.device
         ns = len(scales)
         sums = torch.empty(ns, 3, device=dev, dtype=torch.float32)
+        if _stft_fused_ok(scales, t, rows):
+            # transform inside the kernel (stft_loss.hip): nothing but the two waveforms is read, nothing but 3 sums per
+            # scale written; the backward recomputes the spectra from the saved waveforms
+            inv_n = []
+            for i, (n_fft, win) in enumerate(zip(scales, windows)):
+                win = _chk(win, "window")
+                nbytes = L.lib.rh_stft_loss_workspace_bytes(n_fft, t, rows)
+                ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+                L.check(L.lib.rh_stft_loss_fwd_f32(L.ptr(x), L.ptr(y), L.ptr(win), L.ptr(_twiddle(n_fft, dev)), rows, t, n_fft, eps,
+                                                   sums[i].data_ptr(), L.ptr(ws), nbytes, s), "stft_loss_fwd")
+                inv_n.append(1.0 / (rows * (t // (n_fft // 4) + 1) * (n_fft // 2 + 1)))
+            key = (tuple(inv_n), str(dev))
+            if key not in _INV_N and not torch.cuda.is_current_stream_capturing():
+                _INV_N[key] = torch.tensor(inv_n, dtype=torch.float32, device=dev)
+            inv = _inv_n_cached(tuple(inv_n), dev)
+            out = torch.empty((), device=dev, dtype=torch.float32)
+            L.check(L.lib.rh_spectral_total_f32(L.ptr(sums), L.ptr(inv), ns, L.ptr(out), s), "spectral_total")
+            ctx.save_for_backward(sums, *windows, x, y)
+            ctx.meta = (rows, t, float(eps), tuple(int(v) for v in scales))
+            ctx.fused = True
+            return out
+        ctx.fused = False
         nbytes = L.lib.rh_spectral_distance_workspace_bytes()
         ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
         saved = []
@@ -1102,6 +1124,13 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
         dev = g.device
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         outs = [torch.empty(rows, t, device=dev, dtype=torch.float32) if nd else None for nd in need]
+        if ctx.fused:
+            x, y = specs
+            for i, n_fft in enumerate(scales):
+                L.check(L.lib.rh_stft_loss_bwd_f32(L.ptr(x), L.ptr(y), L.ptr(windows[i]), L.ptr(_twiddle(n_fft, dev)), rows, t, n_fft,
+                                                   eps, sums[i].data_ptr(), L.ptr(g), None if outs[0] is None else L.ptr(outs[0]),
+                                                   None if outs[1] is None else L.ptr(outs[1]), 1 if i > 0 else 0, s), "stft_loss_bwd")
+            return (outs[0], outs[1], None, None, None) + (None,) * ns
         for i, n_fft in enumerate(scales):
             sx, sy = specs[2 * i], specs[2 * i + 1]
             hop = n_fft // 4
@@ -1126,6 +1155,27 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
 
 
 _INV_N = {}
+_TWIDDLE = {}
+
+
+def _twiddle(n: int, dev) -> Tensor:
+    """e^{-2 pi i k / n}, k < n, as (n, 2) f32 (rounded from f64), made once per size and device outside any capture."""
+    k = (int(n), str(dev))
+    t = _TWIDDLE.get(k)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("rave_amd multiscale_stft_distance: first call inside a hipGraph capture (run one eager step first)")
+        import math
+        a = torch.arange(n, dtype=torch.float64) * (-2.0 * math.pi / n)
+        t = _TWIDDLE[k] = torch.stack([torch.cos(a), torch.sin(a)], -1).to(torch.float32).to(dev).contiguous()
+    return t
+
+
+def _stft_fused_ok(scales, t: int, rows: int) -> bool:
+    import os
+    if os.environ.get("RH_STFT_FUSED", "1") == "0":      # 0: framing kernels + rocFFT + spectral kernels (the older path)
+        return False
+    return all(L.lib.rh_stft_loss_supported(int(n), int(n) // 4, int(t), int(rows)) for n in scales)
 
 
 def _inv_n_cached(key, dev):

@@ -356,8 +356,12 @@ def test_multiscale_stft_distance_node_equals_the_per_scale_nodes(dev):
         x = (0.3 * torch.randn(rows, t, generator=gen)).to(dev).requires_grad_(True)
         y = (0.3 * torch.randn(rows, t, generator=gen)).to(dev).requires_grad_(True)
         wins = [torch.hann_window(s, device=dev) for s in scales]
-        d1 = R.multiscale_stft_distance(x, y, wins, scales, 1e-7)
-        gx1, gy1 = torch.autograd.grad(d1, (x, y))
+        os.environ["RH_STFT_FUSED"] = "0"       # the framing + rocFFT form of the node (the in-kernel transform: test_gpu_stft_loss.py)
+        try:
+            d1 = R.multiscale_stft_distance(x, y, wins, scales, 1e-7)
+            gx1, gy1 = torch.autograd.grad(d1, (x, y))
+        finally:
+            os.environ.pop("RH_STFT_FUSED", None)
         d2 = 0.
         for s, w in zip(scales, wins):
             d2 = d2 + R.stft_distance(R.stft_frames(x, w, s, s // 4), R.stft_frames(y, w, s, s // 4), 1e-7)
@@ -368,6 +372,8 @@ def test_multiscale_stft_distance_node_equals_the_per_scale_nodes(dev):
         ref = LS.AudioDistanceV1(partial(LS.MultiScaleSTFT, scales=scales, magnitude=True), 1e-7)
         d3 = ref(x.detach().cpu().unsqueeze(1), y.detach().cpu().unsqueeze(1))["spectral_distance"]
         assert abs(float(d1) - float(d3)) <= 2e-5 * abs(float(d3))
+        d4 = R.multiscale_stft_distance(x, y, wins, scales, 1e-7)        # default: transform inside the kernel
+        assert abs(float(d4) - float(d3)) <= 2e-5 * abs(float(d3))
 
 
 @pytest.mark.parametrize("causal", [False, True])
