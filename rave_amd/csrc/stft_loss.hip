@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void stft_loss_finalize_kernel(const float* __
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const StftP p) {
+__global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
     typedef Fft<N> F;
     constexpr int TPF = F::TPF, G = F::G, H = N / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -440,9 +440,6 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const StftP p) {
     }
 }
 
-// hop blocks per workgroup.  2048: 8 (one transform at a time); else cb + 3 = 8 G, so that every phase of an interior
-// workgroup is exactly two rounds of G transforms: 1024 -> 13, 512 -> 29, 256 -> 61, 128 -> 125
-constexpr int cb_of(int n) { return n == 2048 ? 8 : 8 * (256 / (n / 8)) - 3; }
 constexpr int kTailMin = 6;       // a remainder shorter than this joins the previous workgroup (the last one must own the
                                   // whole right margin and the samples it folds onto: n + 1 samples = 4 blocks + 1)
 
@@ -456,6 +453,46 @@ int chunks_of(int n_blocks, int cb) {
     const int rem = n_blocks - c * cb;
     if (c == 0 || rem >= kTailMin) ++c;
     return c;
+}
+
+// Hop blocks per workgroup of the backward kernel.  A workgroup of nb blocks transforms nb + 3 frames (3 reach in from the
+// left), in four phases of ceil(frames of the phase / G) rounds of G transforms side by side; its LDS image grows with nb
+// and bounds the workgroups per CU.  Candidates are the sizes whose phases are whole rounds (nb + 3 = 4 G m) plus "the
+// whole row"; the estimate is (residency waves of the grid) x (rounds of the longest workgroup).
+int rounds_of(int blocks, int first_frame_cut, int G) {
+    int r = 0;
+    const int frames = blocks + 3 - first_frame_cut;
+    for (int ph = 0; ph < 4; ++ph) r += ((frames - ph + 3) / 4 + G - 1) / G;
+    return r;
+}
+int choose_cb(int n_fft, int n_blocks, long rows) {
+    const int G = 256 / (n_fft / 8), H = n_fft / 4;
+    const size_t zb = (size_t)G * (n_fft + n_fft / 8) * 8;
+    int best = 0;
+    double best_cost = 1e30;
+    for (int m = 1; m <= 64; ++m) {
+        int cb = 4 * G * m - 3;
+        if (cb < kTailMin) continue;
+        if (cb > n_blocks) cb = n_blocks;
+        const int nch = chunks_of(n_blocks, cb);
+        const int last = n_blocks - (nch - 1) * cb;
+        const int big = last > cb ? last : cb;
+        const size_t lds = zb + 2ul * big * H * 4;
+        if (lds > 150 * 1024) break;
+        int per_cu = (int)(160 * 1024 / lds);
+        per_cu = per_cu > 3 ? 3 : per_cu;                               // __launch_bounds__(256, 3): <= 168 VGPRs
+        const double wgs = (double)rows * nch, slots = 256.0 * per_cu;
+        const int r_first = rounds_of(nch == 1 ? n_blocks : cb, 3, G);   // the first workgroup has no frames to its left
+        const int r_mid = nch > 2 ? rounds_of(cb, 0, G) : 0;
+        const int r_last = nch > 1 ? rounds_of(last, 0, G) : 0;
+        const int r_max = r_first > r_mid ? (r_first > r_last ? r_first : r_last) : (r_mid > r_last ? r_mid : r_last);
+        // whole residency waves at the longest workgroup's length, + a per-round cost that falls with the occupancy
+        const double waves = wgs <= slots ? 1.0 : wgs / slots + 0.5;
+        const double cost = waves * r_max * (1.0 + 0.5 / per_cu) + 0.15 * nch;      // + set-up / write-out per workgroup
+        if (cost < best_cost) { best_cost = cost; best = cb; }
+        if (cb == n_blocks) break;
+    }
+    return best ? best : n_blocks;
 }
 
 template <int N>
@@ -542,7 +579,7 @@ extern "C" int rh_stft_loss_bwd_f32(const float* x, const float* y, const float*
     p.rows = (int)rows; p.t_len = t_len; p.n_frames = t_len / (n_fft / 4) + 1; p.eps = eps;
     const int H = n_fft / 4;
     p.n_blocks = (t_len + n_fft + H - 1) / H;
-    p.cb = cb_of(n_fft);
+    p.cb = choose_cb(n_fft, p.n_blocks, rows);
     p.sums = sums; p.gout = grad_out;
     p.inv_n = (float)(1.0 / ((double)rows * p.n_frames * (n_fft / 2 + 1)));
     p.dx = dx; p.dy = dy; p.accumulate = accumulate;
