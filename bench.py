@@ -333,10 +333,12 @@ def main():
             os.environ["RH_BWD_SIDE_STREAM"] = side_env
         fence()
     if rank == 0 and rec is not None:
+        # per kind: [launches, flop, bytes, kernel ms (the main kernel's own start/stop timestamps), call ms (event bracket
+        # around the whole C-ABI call: + split-K finalize / partial-sum reduction launches + event overhead)]
         agg = {}
-        for kind, fl, by, ms in rec:
-            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
+        for kind, fl, by, kms, cms in rec:
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += by; a[3] += (kms if kms is not None else cms); a[4] += cms
         # every launch is priced against the peak of the instruction it issues: conv_x6_kernel = exact f32 as six
         # v_mfma_f32_32x32x16_bf16 per product block (2.5 PF / 6 = 417 TFLOP/s f32-equivalent); the f32-input MFMA
         # kernels (conv_igemm_dma_kernel forward / data gradient of the few geometries x6 does not take, and
@@ -347,14 +349,15 @@ def main():
                    "conv_wgrad[f32]": "wgrad_dma_kernel", "conv_wgrad[x6]": "wgrad_x6_kernel"}
         byk = {}
         for k, v in agg.items():
-            a = byk.setdefault(kern_of.get(k, k), [0, 0.0, 0.0, 0.0, peak_of(k)])
-            for i in range(4):
+            a = byk.setdefault(kern_of.get(k, k), [0, 0.0, 0.0, 0.0, 0.0, peak_of(k)])
+            for i in range(5):
                 a[i] += v[i]
         dom_name = max(byk, key=lambda k: byk[k][3])
-        n, fl, by, ms, peak = byk[dom_name]
+        n, fl, by, ms, cms, peak = byk[dom_name]
         out["roofline"] = {
             "bound": "mfma", "kernel": dom_name + (" (weight-gradient launches)" if dom_name.startswith("wgrad")
-                                                   else " (forward + data-gradient launches)"),
+                                                   else " (forward + data-gradient launches; 6 of them per step are the fused "
+                                                        "Residual(DilatedUnit) kernel unit_x6_kernel, same main loop)"),
             "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": fl / (ms * 1e-3) / peak, "frac_vs_exact_f32_peak": fl / (ms * 1e-3) / F32_MFMA_PEAK,
             "frac_vs_sustained_mfma_rate": (fl / (ms * 1e-3) / X6_MFMA_SUSTAINED) if peak == X6_MFMA_PEAK else None,
@@ -366,18 +369,22 @@ def main():
                             "timed process); null if that file is absent",
             "algorithmic_bytes_per_launch": by / n,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
+            "avg_call_ms": cms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9,
-            "timing_note": "per-launch HIP events in eager replays of the step with the side stream off (one kernel at a time); "
-                           "matches profiles/round3_kernel_stats_step_b32.md (rocprofv3 of `bench.py --no-graph` with "
-                           "RH_BWD_SIDE_STREAM=0); the timed region itself overlaps the weight-gradient branch on a second stream",
+            "timing_note": "avg_launch_ms = the kernel's own duration: every launch is dispatched with a pair of HIP events as "
+                           "its start / stop events (rh_set_kernel_events -> hipExtLaunchKernelGGL, on the launch stream), the "
+                           "timestamps rocprofv3 reads -- compare profiles/round3_kernel_stats_step_b32.md (rocprofv3 "
+                           "--kernel-trace --stats of `bench.py --no-graph`, RH_BWD_SIDE_STREAM=0).  Eager replays of the step "
+                           "with the side stream off (one kernel at a time); the timed region itself overlaps the "
+                           "weight-gradient branch on a second stream.  avg_call_ms = event bracket around the whole C-ABI "
+                           "call: + the split-K finalize launch where the plan splits K, + event overhead",
             "note": "f32 in / f32 accumulate everywhere; peak = that of the instruction the kernel issues (conv_x6_kernel: "
                     "every f32 split exactly into 3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block -> 2.5 PF / 6 = "
-                    "417 TFLOP/s f32-equivalent; f32-input MFMA kernels: 157.3); HIP events on the launch stream around "
-                    "every launch of the kernel with the largest total time",
+                    "417 TFLOP/s f32-equivalent; f32-input MFMA kernels: 157.3)",
         }
-        out["kernels"] = {k: ({"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
-                               "tflops": v[1] / (v[3] * 1e-3) / 1e12, "peak_tflops": v[4] / 1e12,
-                               "frac_of_issued_peak": v[1] / (v[3] * 1e-3) / v[4]} if not k.endswith("[valu]") else
+        out["kernels"] = {k: ({"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "call_ms_per_step": v[4] / reps,
+                               "tflops": v[1] / (v[3] * 1e-3) / 1e12, "peak_tflops": v[5] / 1e12,
+                               "frac_of_issued_peak": v[1] / (v[3] * 1e-3) / v[5]} if not k.endswith("[valu]") else
                               # vector-ALU first-layer kernels (conv_smallc.hip): one pass over a C_out x L tensor
                               {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "bound": "hbm",
                                "algorithmic_TBps": v[2] / (v[3] * 1e-3) / 1e12, "peak_TBps": HBM_PEAK / 1e12,
@@ -389,7 +396,7 @@ def main():
                                         "time, each further one ~1.2 ns (tools/probe/mfma_clock.hip, "
                                         "profiles/round3_probe_mfma_clock.txt).  frac_vs_sustained_mfma_rate prices the kernel "
                                         "against that measured rate")
-        out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps,
+        out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "call_ms_per_step": v[4] / reps,
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
                                       "algorithmic_GBps": v[2] / (v[3] * 1e-3) / 1e9} for k, v in agg.items()}
         # ---- forward-only leg of the north-star target (PQMF + conv stacks, no_grad)

@@ -359,6 +359,18 @@ int rh_stft_loss_bwd_f32(const float* x, const float* y, const float* window, co
                          int32_t t_len, int32_t n_fft, float eps, const float* sums, const float* grad_out, float* dx,
                          float* dy, int32_t accumulate, rh_stream_t stream);
 
+/* Measurement hook (bench.py's roofline leg; not part of the reference interface): arm a pair of HIP events (hipEvent_t,
+ * created by the caller with timing enabled) for the calling thread's NEXT main kernel launch -- the convolution /
+ * weight-gradient kernel of rh_conv1d_fwd_f32 / _bwd_data_f32 / _bwd_weight_f32 / rh_residual_unit_fwd_f32, not its split-K
+ * finalize or reduction launches.  The kernel is dispatched with the events as its own start / stop events, so
+ * hipEventElapsedTime(start, stop) is the duration rocprofv3 reports for that dispatch.  rh_kernel_events_used() tells whether
+ * a launch consumed the pair (and disarms it). */
+int rh_set_kernel_events(void* start_event, void* stop_event);
+int rh_kernel_events_used(void);
+int rh_event_create(void** event);                                   /* hipEventCreate (timing enabled) */
+int rh_event_destroy(void* event);
+int rh_event_elapsed_ms(void* start_event, void* stop_event, float* ms);   /* after the stream has been synchronised */
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,11 @@ def _load() -> C.CDLL:
         "rh_stft_frame_bwd_f32": ([P, P, I64, I32, I32, I32, I32, P, P], C.c_int),
         "rh_stft_frame_bwd_acc_f32": ([P, P, I64, I32, I32, I32, I32, P, I32, P], C.c_int),
         "rh_spectral_total_f32": ([P, P, I32, P, P], C.c_int),
+        "rh_set_kernel_events": ([P, P], C.c_int),
+        "rh_kernel_events_used": ([], C.c_int),
+        "rh_event_create": ([C.POINTER(C.c_void_p)], C.c_int),
+        "rh_event_destroy": ([P], C.c_int),
+        "rh_event_elapsed_ms": ([P, P, C.POINTER(C.c_float)], C.c_int),
         "rh_stft_loss_supported": ([I32, I32, I32, I64], C.c_int),
         "rh_stft_loss_workspace_bytes": ([I32, I32, I64], I64),
         "rh_stft_loss_fwd_f32": ([P, P, P, P, I64, I32, I32, F, P, P, I64, P], C.c_int),

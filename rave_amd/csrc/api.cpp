@@ -23,5 +23,37 @@ int rh_check_launch(const char* what) {
     return RH_OK;
 }
 
+thread_local hipEvent_t rh_ev_start = nullptr, rh_ev_stop = nullptr;
+thread_local int rh_ev_used = 0;
+
+extern "C" int rh_set_kernel_events(void* start, void* stop) {
+    rh_ev_start = (hipEvent_t)start;
+    rh_ev_stop = (hipEvent_t)stop;
+    rh_ev_used = 0;
+    return RH_OK;
+}
+// 1 if a main-kernel launch took the events since rh_set_kernel_events (also disarms them)
+extern "C" int rh_kernel_events_used(void) {
+    const int u = rh_ev_used;
+    rh_ev_start = rh_ev_stop = nullptr;
+    rh_ev_used = 0;
+    return u;
+}
+
+extern "C" int rh_event_create(void** ev) {
+    RH_REQUIRE(ev, RH_ERR_INVALID, "event_create: null pointer");
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { rh_set_error("event_create: hipEventCreate failed"); return RH_ERR_INVALID; }
+    *ev = e;
+    return RH_OK;
+}
+extern "C" int rh_event_destroy(void* ev) { return ev && hipEventDestroy((hipEvent_t)ev) != hipSuccess ? RH_ERR_INVALID : RH_OK; }
+extern "C" int rh_event_elapsed_ms(void* start, void* stop, float* ms) {
+    RH_REQUIRE(start && stop && ms, RH_ERR_INVALID, "event_elapsed: null pointer");
+    const hipError_t e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (e != hipSuccess) { rh_set_error("event_elapsed: %s", hipGetErrorString(e)); return RH_ERR_INVALID; }
+    return RH_OK;
+}
+
 extern "C" int rh_version(void) { return RH_VERSION; }
 extern "C" const char* rh_last_error(void) { return g_err; }

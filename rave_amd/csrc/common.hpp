@@ -1,6 +1,7 @@
 // Shared device/host helpers for librave_hip (gfx950 only: wave = 64 lanes, f32-input MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/rave_hip.h"
 
@@ -9,6 +10,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void rh_set_error(const char* fmt, ...);
 int rh_check_launch(const char* what);
+
+// Measurement hook (rh_set_kernel_events, bench.py's roofline leg): the next MAIN kernel launch of this thread -- the
+// convolution / weight-gradient kernel itself, not its split-K finalize or reduction launches -- carries the pair of HIP
+// events as its own start / stop events (hipExtLaunchKernelGGL: the dispatch's own timestamps, what rocprofv3 reports).
+extern thread_local hipEvent_t rh_ev_start, rh_ev_stop;
+extern thread_local int rh_ev_used;
+#ifdef __HIP__
+template <typename K, typename... A>
+inline void rh_launch_main(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+    if (rh_ev_start) {
+        hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, stream, rh_ev_start, rh_ev_stop, 0, args...);
+        rh_ev_start = rh_ev_stop = nullptr;
+        rh_ev_used = 1;
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, args...);
+    }
+}
+#endif
 
 #define RH_REQUIRE(cond, code, ...)      \
     do {                                 \

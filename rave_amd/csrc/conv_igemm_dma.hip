@@ -487,7 +487,7 @@ int launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t
     p.part = (float*)ws;
     auto launch = [&](auto kern) {
         dim3 grid(col_tiles, rh_cdiv(p.M, BM), p.nphase * p.ksplit);
-        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+        rh_launch_main(kern, grid, dim3(WM * WN * 64), lds, stream, p);
     };
     auto go = [&](auto kern) {
         static std::once_flag once;

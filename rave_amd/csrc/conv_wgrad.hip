@@ -549,7 +549,7 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
                 auto go = [&](auto kern) {
                     static std::once_flag once;
                     std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-                    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+                    rh_launch_main(kern, grid, dim3(WM * WN * 64), lds, stream, p);
                 };
                 if (p.r_act == RH_ACT_LEAKY) go(wgrad_dma_kernel<TM, TN, WM, WN, true, false>);
                 else if (p.s_act == RH_ACT_LEAKY) go(wgrad_dma_kernel<TM, TN, WM, WN, false, true>);
@@ -571,7 +571,7 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     dim3 grid(w.ct, w.mt, w.Z);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+    rh_launch_main(kern, grid, dim3(WM * WN * 64), lds, stream, p);
     return rh_check_launch("conv1d_bwd_weight");
 }
 

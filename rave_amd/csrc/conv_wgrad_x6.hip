@@ -326,7 +326,7 @@ void go2(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    hipLaunchKernelGGL(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), lds, stream, p);
+    rh_launch_main(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), lds, stream, p);
 }
 
 template <int TM, int WM>

@@ -375,7 +375,7 @@ extern "C" int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1
         std::call_once(once, [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, u);
+        rh_launch_main(kern, grid, dim3(256), lds, (hipStream_t)stream, u);
     };
     const int tm = p.M / 32;
     if (tm == 1) go(unit_x6_kernel<1, 2>);

@@ -17,8 +17,13 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_SNAKE  # noqa: F401
 Tensor = torch.Tensor
 
 
-# ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ------
+# ---- optional per-launch timing (bench.py roofline leg) -------------------------------------------------------------
+# Two clocks per launch: (a) the MAIN kernel's own start / stop timestamps -- the library dispatches it with a pair of HIP
+# events attached (rh_set_kernel_events -> hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports for that dispatch;
+# (b) a torch event bracket on the launch stream around the whole C-ABI call (main kernel + its split-K finalize /
+# partial-sum reduction launches + event overhead).
 _PROFILE = None
+_EVENT_POOL = []
 
 
 def profile_begin() -> None:
@@ -26,12 +31,44 @@ def profile_begin() -> None:
     _PROFILE = []
 
 
+def _hip_event():
+    if _EVENT_POOL:
+        return _EVENT_POOL.pop()
+    h = C.c_void_p()
+    L.check(L.lib.rh_event_create(C.byref(h)), "event_create")
+    return h
+
+
 def profile_end():
-    """Returns [(kind, flops, bytes, milliseconds)] for every conv launch since profile_begin()."""
+    """[(kind, flops, bytes, kernel_ms, call_ms)] for every conv launch since profile_begin(): kernel_ms = the main kernel's
+    own duration (None where the launch took a kernel without the hook), call_ms = the whole call on its stream."""
     global _PROFILE
     rec, _PROFILE = _PROFILE, None
     torch.cuda.synchronize()
-    return [(k, f, b, e0.elapsed_time(e1)) for (k, f, b, e0, e1) in rec]
+    out = []
+    for (k, f, b, e0, e1, h0, h1, used) in rec:
+        kms = None
+        if used:
+            ms = C.c_float()
+            if L.lib.rh_event_elapsed_ms(h0, h1, C.byref(ms)) == 0:
+                kms = ms.value
+        _EVENT_POOL.extend((h0, h1))
+        out.append((k, f, b, kms, e0.elapsed_time(e1)))
+    return out
+
+
+def _timed(kind, f, b, fn):
+    """Run one C-ABI launch under both clocks (profile mode only)."""
+    h0, h1 = _hip_event(), _hip_event()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.lib.rh_set_kernel_events(h0, h1)
+    r = fn()
+    used = L.lib.rh_kernel_events_used()
+    e1.record()
+    _PROFILE.append((kind, f, b, e0, e1, h0, h1, used))
+    return r
 
 
 # ---- optional launch-plan log (parity tests: which template instance / K split / layout did each conv launch get?)
@@ -134,14 +171,8 @@ def _launch(kind: str, d, fn, has_bias=False, has_add=False):
         kind += _FAMILY.get(fam, "[f32]")
     elif kind == "conv_wgrad":
         kind += _FAMILY.get(L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(d)), "[f32]")
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = fn()
-    e1.record()
     f, b = _conv_cost(d)
-    _PROFILE.append((kind, f, b, e0, e1))
-    return r
+    return _timed(kind, f, b, fn)
 
 
 def _chk(t: Optional[Tensor], name: str) -> Optional[Tensor]:
@@ -210,14 +241,9 @@ def _unit_fwd(d3, d1, x, wp3, wp1, h, y, s):
     if _PROFILE is None:
         rc = run(y, h)
     else:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = run(y, h)
-        e1.record()
         f3, b3 = _conv_cost(d3)
         f1, b1 = _conv_cost(d1)
-        _PROFILE.append(("conv_fwd[x6]", f3 + f1, b3 + b1, e0, e1))
+        rc = _timed("conv_fwd[x6]", f3 + f1, b3 + b1, lambda: run(y, h))
     if rc == 0 and _SHADOW is not None:
         # the two-launch path on the exact-f32 kernels, same operands
         h2, y2 = torch.empty_like(x), torch.empty_like(x)
@@ -647,14 +673,8 @@ def _conv2d_cost(d: "L.Conv2dDesc"):
 def _launch2(kind: str, d, fn):
     if _PROFILE is None:
         return fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = fn()
-    e1.record()
     f, b = _conv2d_cost(d)
-    _PROFILE.append((kind, f, b, e0, e1))
-    return r
+    return _timed(kind, f, b, fn)
 
 
 class _Conv2dFn(torch.autograd.Function):

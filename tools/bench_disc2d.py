@@ -68,7 +68,7 @@ step()
 rec = ops.profile_end()
 ops._launch2, ops._launch = orig, orig1
 agg = OrderedDict()
-for key, (kind, fl, by, ms) in zip(recs, rec):
+for key, (kind, fl, by, kms, ms) in zip(recs, rec):     # ms = the whole call (main kernel + finalize / reduction launches)
     if key[0] == "(1d)":       # the recorded kind carries the kernel family tag ([x6] / [f32])
         key = (kind + "(1d)",) + key[1:]
     a = agg.setdefault(key, [0, 0.0, 0.0])
