@@ -23,6 +23,8 @@ if has layers; then
   timeout 200 python tools/bench_layers.py < /dev/null > $O/layers.log 2>&1
   NIT=10 timeout 200 python tools/check_x6.py < /dev/null > $O/check_x6.log 2>&1
   timeout 100 python tools/bench_pqmf.py < /dev/null > $O/pqmf.log 2>&1
+  timeout 100 python tools/bench_stft_loss.py < /dev/null > $O/stft_loss.log 2>&1
+  timeout 100 python tools/debug/split_chain.py < /dev/null > $O/split_chain.log 2>&1
 fi
 if has prof; then
   (cd /tmp && RH_BWD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/prof.log 2>&1 < /dev/null)
@@ -49,7 +51,7 @@ if has disc; then
   for w in v2 encodec descript; do N=32; [ $w = v2 ] && N=64; WHICH=$w N=$N timeout 300 python tools/bench_disc2d.py < /dev/null > $O/disc_$w.log 2>&1; done
 fi
 for f in bench_n1 bench_n1_eager bench_dist1 bench_gan bench_gan_skip bench_discrete bench_v3; do [ -f $O/$f.log ] && { echo "== $f"; grep "^{" $O/$f.log | tail -1 | cut -c1-330; }; done
-[ -f $O/layers.log ] && tail -2 $O/layers.log; [ -f $O/check_x6.log ] && tail -1 $O/check_x6.log; [ -f $O/pqmf.log ] && grep "kernel level\|module" $O/pqmf.log
+[ -f $O/layers.log ] && tail -2 $O/layers.log; [ -f $O/check_x6.log ] && tail -1 $O/check_x6.log; [ -f $O/pqmf.log ] && grep "kernel level\|module" $O/pqmf.log; [ -f $O/stft_loss.log ] && grep "sum over" $O/stft_loss.log
 [ -f $O/kernel_stats_step_b32_graph.md ] && { head -12 $O/kernel_stats_step_b32_graph.md; tail -1 $O/kernel_stats_step_b32_graph.md; }
 [ -f $O/pmc_traffic.log ] && cat $O/pmc_traffic.log | head -80
 [ -f $O/disc_v2.log ] && grep "TOTAL\|fwd+bwd" $O/disc_v2.log $O/disc_encodec.log $O/disc_descript.log
