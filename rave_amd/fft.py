@@ -34,10 +34,8 @@ def _load():
     return _lib
 
 
-def _plan(kind: int, n: int, batch: int, device: torch.device, lane: int = 0) -> int:
-    # `lane`: a plan owns its work area, so transforms that may run CONCURRENTLY on two streams (the x branch of the
-    # spectral losses on the side stream) need plans of their own
-    key = (kind, n, batch, device.index or 0, lane)
+def _plan(kind: int, n: int, batch: int, device: torch.device) -> int:
+    key = (kind, n, batch, device.index or 0)
     p = _plans.get(key)
     if p is None:
         h = C.c_void_p()
@@ -50,7 +48,7 @@ def _plan(kind: int, n: int, batch: int, device: torch.device, lane: int = 0) ->
     return p
 
 
-def rfft_last(frames: torch.Tensor, lane: int = 0) -> torch.Tensor:
+def rfft_last(frames: torch.Tensor) -> torch.Tensor:
     """rfft over the last dim of a contiguous fp32 GPU tensor; the input buffer may be overwritten."""
     n = frames.shape[-1]
     if not _load() or n % 2:
@@ -58,7 +56,7 @@ def rfft_last(frames: torch.Tensor, lane: int = 0) -> torch.Tensor:
     batch = frames.numel() // n
     out = torch.empty(frames.shape[:-1] + (n // 2 + 1,), device=frames.device, dtype=torch.complex64)
     with torch.cuda.device(frames.device):
-        p = _plan(_HIPFFT_R2C, n, batch, frames.device, lane)
+        p = _plan(_HIPFFT_R2C, n, batch, frames.device)
         _lib.hipfftSetStream(p, torch.cuda.current_stream().cuda_stream)
         rc = _lib.hipfftExecR2C(p, frames.data_ptr(), out.data_ptr())
     if rc != 0:

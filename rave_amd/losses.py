@@ -73,25 +73,15 @@ class AudioDistanceV1(nn.Module):
         self.multiscale_stft = multiscale_stft()
         self.log_epsilon = log_epsilon
 
-    def precompute(self, x):
-        """Start the STFTs of the TARGET ``x`` on the side stream (rave_amd.ops.stft_precompute); pass the result as
-        ``pre=`` to ``forward`` with the same ``x``.  None on the CPU / with the side stream disabled."""
-        if not x.is_cuda:
-            return None
-        from . import ops
-        ms = self.multiscale_stft
-        return ops.stft_precompute(x.reshape(-1, x.shape[-1]), [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales)
-
-    def forward(self, x, y, pre=None):
+    def forward(self, x, y):
         if x.is_cuda:
-            # fused path: magnitude, both distances and their reductions in one HIP kernel per scale
-            # (rh_spectral_distance_*), the STFTs themselves on rocFFT
+            # STFT, magnitudes, both distances and their reductions inside one HIP kernel per scale (rh_stft_loss_*_f32)
             from . import ops
             ms = self.multiscale_stft
             xr, yr = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
             # all scales in ONE autograd node: the scale sum and the per-signal gradient accumulation happen inside
             distance = ops.multiscale_stft_distance(xr, yr, [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales,
-                                                    float(self.log_epsilon), pre)
+                                                    float(self.log_epsilon))
             return {"spectral_distance": distance}
         stfts_x = self.multiscale_stft(x)
         stfts_y = self.multiscale_stft(y)

@@ -215,12 +215,6 @@ class RAVE(nn.Module):
                 self._rf_host = tuple(int(v) for v in self.receptive_field.tolist())
             rf = getattr(self, "_rf_host", (0, 0))
         x_mb_loss = valid_signal_crop(x_multiband, rf[0], rf[1]) if rf[0] + rf[1] else x_multiband
-        # the targets of both spectral distances are known now: their STFTs (bandwidth-bound) start on the side stream and
-        # run beside the encoder / decoder forward (matrix-bound); plumbing, same kernels and values
-        pre_mb = pre_fb = None
-        if batch.is_cuda and hasattr(self.audio_distance, "precompute"):
-            pre_mb = self.multiband_audio_distance.precompute(x_mb_loss)
-            pre_fb = self.audio_distance.precompute(x_raw)
         z = self.encoder(x_multiband)
         z, reg = self.encoder.reparametrize(z, eps)[:2]
 
@@ -234,12 +228,10 @@ class RAVE(nn.Module):
         x_multiband = x_mb_loss
 
         distances = {}
-        kw_mb = {"pre": pre_mb} if pre_mb is not None else {}
-        kw_fb = {"pre": pre_fb} if pre_fb is not None else {}
-        multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband, **kw_mb)
+        multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
         for k, v in multiband_distance.items():
             distances[f"multiband_{k}"] = self.weights["multiband_audio_distance"] * v
-        fullband_distance = self.audio_distance(x_raw, y_raw, **kw_fb)
+        fullband_distance = self.audio_distance(x_raw, y_raw)
         for k, v in fullband_distance.items():
             distances[f"fullband_{k}"] = self.weights["audio_distance"] * v
 

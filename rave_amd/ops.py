@@ -292,11 +292,9 @@ def _side_enabled() -> bool:
     return os.environ.get("RH_BWD_SIDE_STREAM", "1") != "0"
 
 
-def _side_stream(device, lane: int = 0):
-    """lane 0: the weight-gradient branch of the backward pass; lane 1: the spectral-loss target STFTs of the forward
-    pass.  Two streams: re-forking a capture stream after it has been joined once mid-capture gave graphs whose replays
-    raced (measured: tools/debug/precompute_identity.py); with one fork / join pattern per stream they do not."""
-    k = (device.index if device.index is not None else torch.cuda.current_device(), lane)
+def _side_stream(device):
+    """The stream of the weight-gradient branch of the backward pass (one per device)."""
+    k = device.index if device.index is not None else torch.cuda.current_device()
     st = _SIDE.get(k)
     if st is None:
         st = _SIDE[k] = torch.cuda.Stream(device=device)
@@ -346,7 +344,7 @@ class _OnSide:
         self.device = device
         self.tensors = [t for t in tensors if t is not None]
         import os
-        self.active = allow and _side_enabled() and os.environ.get("RH_WGRAD_SIDE", "1") != "0"
+        self.active = allow and _side_enabled()
 
     def __enter__(self):
         if not self.active:
@@ -1009,47 +1007,6 @@ def stft_distance(frames_x: Tensor, frames_y: Tensor, eps: float) -> Tensor:
     return _StftDistanceFn.apply(frames_x, frames_y, eps)
 
 
-class StftPre:
-    """Spectra of the TARGET signal of a multi-scale spectral distance, computed ahead of time on the side stream
-    (``stft_precompute``): the target (the input audio / its PQMF bands) is known at the start of a training step, so its
-    framing + FFT passes (bandwidth-bound) can run beside the encoder / decoder forward (matrix-bound)."""
-
-    def __init__(self, specs, shape, scales, stream):
-        self.specs, self.shape, self.scales, self.stream = specs, tuple(shape), tuple(scales), stream
-
-
-def stft_precompute(x: Tensor, windows, scales):
-    """Complex STFTs (rows, frames, bins) of ``x`` (rows, T) for every scale, enqueued on the side stream after everything
-    already enqueued on the current one; None when the side stream is disabled (RH_BWD_SIDE_STREAM=0)."""
-    import os
-    # OPT-IN (RH_STFT_PRECOMPUTE=1), off by default: eager steps and graph replays are bit-identical with it alone, and with
-    # the weight-gradient side branch alone, but hipGraph replays of a step that contains BOTH forks come out
-    # nondeterministic in the last bits (tools/debug/precompute_identity.py: 3 of 4 captures, also with two separate side
-    # streams; an immediate join after the fork -- same memory pattern, no concurrency -- is clean).  Unresolved; the
-    # backward branch is the one kept (it is worth more).
-    if not (x.is_cuda and _side_enabled()) or os.environ.get("RH_STFT_PRECOMPUTE", "0") != "1":
-        return None
-    from . import fft as F
-    xd = _chk(x.detach(), "x")
-    rows, t = xd.shape
-    main = torch.cuda.current_stream(xd.device)
-    side = _side_stream(xd.device, lane=1)
-    side.wait_stream(main)
-    specs = []
-    with torch.cuda.stream(side):
-        s = L.stream()
-        for n_fft, win in zip(scales, windows):
-            hop = n_fft // 4
-            nf = t // hop + 1
-            fr = torch.empty(rows, nf, n_fft, device=xd.device, dtype=torch.float32)
-            L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(xd), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
-            specs.append(F.rfft_last(fr, lane=1))
-    xd.record_stream(side)
-    if os.environ.get("RH_STFT_PRE_JOIN", "0") == "1":      # debugging aid: no concurrency, same memory pattern
-        main.wait_stream(side)
-    return StftPre(specs, xd.shape, scales, side)
-
-
 class _MultiScaleStftDistanceFn(torch.autograd.Function):
     """AudioDistanceV1 over ALL scales of MultiScaleSTFT as one autograd node (rave/core.py:269-344): per scale the HIP
     framing kernel, rocFFT R2C and the fused distance kernel; the sum over the scales in one tiny launch; backward: per
@@ -1058,10 +1015,8 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
     backwards) and 4 full-size gradient additions per signal -- ~30 % of the launches of a VAE-phase step."""
 
     @staticmethod
-    def forward(ctx, x, y, eps: float, scales, pre, *windows):
+    def forward(ctx, x, y, eps: float, scales, *windows):
         x = _chk(x, "x"); y = _chk(y, "y")
-        if pre is not None and (pre.shape != tuple(x.shape) or pre.scales != tuple(scales)):
-            pre = None
         if x.shape != y.shape or x.dim() != 2:
             raise RuntimeError("rave_amd multiscale_stft_distance: expects two (rows, T) tensors of equal shape")
         from . import fft as F
@@ -1100,22 +1055,12 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             win = _chk(win, "window")
             hop = n_fft // 4
             nf = t // hop + 1
-            if pre is None:
-                # both signals in one frames buffer: ONE batched R2C per scale
-                fr = torch.empty(2, rows, nf, n_fft, device=dev, dtype=torch.float32)
-                for k, sig in enumerate((x, y)):
-                    L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, fr[k].data_ptr(), s), "stft_frame_fwd")
-                spec = F.rfft_last(fr)
-                sx, sy = spec[0], spec[1]
-            else:
-                # the target's spectra were computed ahead on the side stream (StftPre): only y here; join before the first use
-                fr = torch.empty(rows, nf, n_fft, device=dev, dtype=torch.float32)
-                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(y), L.ptr(win), rows, t, n_fft, hop, nf, L.ptr(fr), s), "stft_frame_fwd")
-                sy = F.rfft_last(fr)
-                sx = pre.specs[i]
-                if i == 0:
-                    torch.cuda.current_stream(dev).wait_stream(pre.stream)
-                sx.record_stream(torch.cuda.current_stream(dev))
+            # both signals in one frames buffer: ONE batched R2C per scale
+            fr = torch.empty(2, rows, nf, n_fft, device=dev, dtype=torch.float32)
+            for k, sig in enumerate((x, y)):
+                L.check(L.lib.rh_stft_frame_fwd_f32(L.ptr(sig), L.ptr(win), rows, t, n_fft, hop, nf, fr[k].data_ptr(), s), "stft_frame_fwd")
+            spec = F.rfft_last(fr)
+            sx, sy = spec[0], spec[1]
             n = sx.numel()
             L.check(L.lib.rh_spectral_distance_fwd_f32(L.ptr(torch.view_as_real(sx)), L.ptr(torch.view_as_real(sy)), n, eps,
                                                        sums[i].data_ptr(), L.ptr(ws), nbytes, s), "spectral_distance_fwd")
@@ -1150,7 +1095,7 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
                 L.check(L.lib.rh_stft_loss_bwd_f32(L.ptr(x), L.ptr(y), L.ptr(windows[i]), L.ptr(_twiddle(n_fft, dev)), rows, t, n_fft,
                                                    eps, sums[i].data_ptr(), L.ptr(g), None if outs[0] is None else L.ptr(outs[0]),
                                                    None if outs[1] is None else L.ptr(outs[1]), 1 if i > 0 else 0, s), "stft_loss_bwd")
-            return (outs[0], outs[1], None, None, None) + (None,) * ns
+            return (outs[0], outs[1], None, None) + (None,) * ns
         for i, n_fft in enumerate(scales):
             sx, sy = specs[2 * i], specs[2 * i + 1]
             hop = n_fft // 4
@@ -1171,7 +1116,7 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             for d_fr, o in parts:
                 L.check(L.lib.rh_stft_frame_bwd_acc_f32(d_fr.data_ptr(), L.ptr(windows[i]), rows, t, n_fft, hop, nf, L.ptr(o),
                                                         1 if i > 0 else 0, s), "stft_frame_bwd")
-        return (outs[0], outs[1], None, None, None) + (None,) * ns
+        return (outs[0], outs[1], None, None) + (None,) * ns
 
 
 _INV_N = {}
@@ -1206,10 +1151,10 @@ def _inv_n_cached(key, dev):
     return _INV_N[k]
 
 
-def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float, pre=None) -> Tensor:
+def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float) -> Tensor:
     """sum over the scales of mean((|Sx|-|Sy|)^2)/mean(|Sx|^2) + mean(|log(|Sx|+eps) - log(|Sy|+eps)|) for (rows, T) signals.
-    ``pre``: ``stft_precompute(x, ...)`` of the same x (its spectra, already under way on the side stream)."""
-    return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), pre, *windows)
+"""
+    return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), *windows)
 
 
 class _AvgPool2Fn(torch.autograd.Function):
