@@ -371,6 +371,21 @@ int rh_event_create(void** event);                                   /* hipEvent
 int rh_event_destroy(void* event);
 int rh_event_elapsed_ms(void* start_event, void* stop_event, float* ms);   /* after the stream has been synchronised */
 
+/* Adam step over many tensors (torch.optim.Adam, weight_decay = 0, amsgrad = False; rave/model.py:226-233): for every
+ * item  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).
+ * `items` is a HOST array (the pointers inside are device pointers; it is consumed during the call: the tables travel in
+ * the kernel arguments, so the call can be recorded into a hipGraph); `lr` and `step` are device scalars -- the call first
+ * advances step[0] by one (t) -- and `aux` is 2 floats of device scratch. */
+typedef struct rh_adam_item {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} rh_adam_item;
+int rh_adam_step_f32(const rh_adam_item* items, int32_t n_items, const float* lr, float beta1, float beta2, float eps,
+                     float* step, float* aux, rh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

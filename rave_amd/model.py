@@ -138,8 +138,15 @@ class RAVE(nn.Module):
             dev = gen_p[0].device
             lr_g, lr_d = torch.tensor(lr_g, device=dev), torch.tensor(lr_d, device=dev)
             kw["capturable"] = True
-        gen_opt = torch.optim.Adam(gen_p, lr_g, (.5, .9), fused=fused, **kw)
-        dis_opt = torch.optim.Adam(dis_p, lr_d, (.5, .9), fused=fused, **kw)
+        import os
+        if fused and os.environ.get("RH_ADAM", "1") != "0":
+            # the same update on one HIP kernel pass at HBM speed (rave_amd/optim.py; RH_ADAM=0: torch's fused kernel)
+            from .optim import FusedAdam
+            gen_opt = FusedAdam(gen_p, lr_g, (.5, .9))
+            dis_opt = FusedAdam(dis_p, lr_d, (.5, .9))
+        else:
+            gen_opt = torch.optim.Adam(gen_p, lr_g, (.5, .9), fused=fused, **kw)
+            dis_opt = torch.optim.Adam(dis_p, lr_d, (.5, .9), fused=fused, **kw)
         self._opts = (gen_opt, dis_opt)
         # rave/model.py:234-236: the generator learning rate decays linearly to 0.1x over phase 1
         self._gen_sched = LinearLR(gen_opt, start_factor=1.0, end_factor=0.1, total_iters=self.warmup)

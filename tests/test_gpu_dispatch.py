@@ -408,3 +408,57 @@ def test_pqmf_second_generation_kernels_are_bit_identical_to_the_first(dev, t_le
     old = run(RH_PQMF_V2=0)
     for a, b in zip(new, old):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_fused_adam_kernel_matches_torch_adam(dev):
+    """rave_amd.optim.FusedAdam (rh_adam_step_f32) against torch.optim.Adam on the same parameters / gradients over 6 steps
+    with a changing learning rate: aligned and unaligned tensors, sizes around the 2048-element workgroup span, a parameter
+    without gradient; then a state_dict round trip into torch's Adam and back."""
+    from rave_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(96, 96, 3), (7,), (2048,), (2049,), (1, 5, 1), (513, 37), (4096 + 3,), (1536, 768, 4)]
+    flat = torch.randn(sum(torch.Size(s).numel() for s in shapes) + 8, generator=gen)
+    base, o = [], 1                                  # views at odd element offsets: 4-byte aligned only
+    for s in shapes:
+        n = torch.Size(s).numel()
+        base.append(flat[o:o + n].reshape(s).clone())
+        o += n
+    pa = [torch.nn.Parameter(b.clone().to(dev)) for b in base] + [torch.nn.Parameter(torch.zeros(5, device=dev))]
+    pb = [torch.nn.Parameter(b.clone().to(dev)) for b in base] + [torch.nn.Parameter(torch.zeros(5, device=dev))]
+    lr_a = torch.tensor(1e-3, device=dev)
+    oa = FusedAdam(pa, lr_a, (.5, .9))
+    ob = torch.optim.Adam(pb, 1e-3, (.5, .9))
+    gbuf = torch.empty(sum(p.numel() for p in pa[:-1]) + 1, device=dev)
+    for it in range(6):
+        o = 1 if it % 2 else 0                       # alternate aligned / unaligned gradient storage
+        for a, b in zip(pa[:-1], pb[:-1]):
+            g = torch.randn(a.shape, generator=gen).to(dev) * (10.0 ** (it - 3))
+            a.grad = gbuf[o:o + a.numel()].view(a.shape)
+            a.grad.copy_(g)
+            b.grad = g.clone()
+            o += a.numel()
+        lr = 1e-3 * (1.0 - 0.1 * it)
+        lr_a.fill_(lr)
+        ob.param_groups[0]["lr"] = lr
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert rel_l2(a.detach(), b.detach()) < 2e-7 if b.abs().max() > 0 else torch.equal(a, b)
+    for a, b in zip(pa[:-1], pb[:-1]):
+        assert rel_l2(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-6
+        assert rel_l2(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6
+    assert float(oa.state[pa[0]]["step"]) == 6.0 and not oa.state[pa[-1]]
+    sd = oa.state_dict()
+    ob2 = torch.optim.Adam(pb, 1e-3, (.5, .9))
+    ob2.load_state_dict(sd)                           # torch's Adam accepts the layout
+    oa2 = FusedAdam(pa, torch.tensor(1e-3, device=dev), (.5, .9))
+    import copy
+    oa2.load_state_dict(copy.deepcopy(ob.state_dict()))   # and back (a copy: load_state_dict keeps same-device tensors by reference); the loaded step counter is adopted
+    for a, b in zip(pa[:-1], pb[:-1]):
+        g = torch.randn(a.shape, generator=gen).to(dev)
+        a.grad = g.clone(); b.grad = g.clone()
+    ob.param_groups[0]["lr"] = 1e-3
+    oa2.param_groups[0]["lr"] = 1e-3                  # (load_state_dict brought torch's float learning rate along: the float path)
+    oa2.step(); ob.step()
+    assert float(oa2.state[pa[0]]["step"]) == 7.0
+    for a, b in zip(pa[:-1], pb[:-1]):
+        assert rel_l2(a.detach(), b.detach()) < 2e-7
