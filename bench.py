@@ -440,13 +440,19 @@ def main():
         ovl = red_gen.bytes_overlapped + (red_dis.bytes_overlapped if red_dis else 0)
         nst = max(args.warmup + args.steps, 1)
         exp_ms = sorted(a.elapsed_time(b) for a, b in ddp_exposed) if ddp_exposed else []
-        out["ddp"] = {"allreduce_bytes_per_step": tot // nst, "buckets": len(red_gen.buckets), "backend": "nccl (RCCL)",
+        # bytes one generator step all-reduces = the flat buckets of the stepping optimizer (a static figure: under graph
+        # replay the Python-side counters only see the warm-up / capture / instrumented eager steps)
+        per_step = sum(b.numel for b in red_gen.buckets) * 4
+        out["ddp"] = {"allreduce_bytes_per_step": per_step, "buckets": len(red_gen.buckets),
+                      "bucket_mib": [round(b.numel * 4 / 2 ** 20, 2) for b in red_gen.buckets], "backend": "nccl (RCCL)",
                       "exposed_ms": exp_ms[len(exp_ms) // 2] if exp_ms else None,
                       "exposed_ms_note": "median GPU time between the end of backward and the last bucket's all-reduce on "
                                          "the compute stream (HIP events around GradReducer.finish() in eager steps)",
+                      "bytes_packed_total": red_gen.bytes_packed + (red_dis.bytes_packed if red_dis else 0),
                       "bytes_packed_per_step": (red_gen.bytes_packed + (red_dis.bytes_packed if red_dis else 0)) // nst,
-                      "bytes_issued_before_backward_ended_per_step": ovl // nst,
                       "overlap_fraction": ovl / tot if tot else None,
+                      "overlap_note": "share of the all-reduce bytes issued from a gradient hook, i.e. while backward still ran "
+                                      "(counted over the steps that ran Python: warm-up, capture, instrumented eager steps)",
                       "buffer_broadcast_bytes_per_step": bufsync.bytes_sent // nst}
         dist.barrier()
         dist.destroy_process_group()

@@ -6,8 +6,9 @@ The reference has no collective call of its own: multi-GPU training is Lightning
 path: clips are independent, so the only exchange is the gradient mean.
 
 * parameters are grouped into ~32 MiB buckets in REVERSE registration order (= the order their
-  gradients become final during backward: discriminator -> decoder -> encoder); every bucket owns ONE
-  persistent flat buffer and every parameter a view into it;
+  gradients become final during backward: discriminator -> decoder -> encoder), the last bucket cut down to <= 4 MiB
+  (its all-reduce is the only one nothing can hide); every bucket owns ONE persistent flat buffer and every parameter a
+  view into it;
 * **gradients live in the buckets**: the weight-gradient / weight-norm backward kernels of the conv operators write
   straight into the parameter's view (rave_amd.ops: ``grad_slot``) and hand that view to autograd, which adopts it as
   ``p.grad`` -- no pack pass before the all-reduce and no copy-back after it (round 2 paid 2 x 126 MB of copies per
@@ -48,24 +49,37 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
-                 process_group=None, overlap: bool = True, force: bool = False):
+                 process_group=None, overlap: bool = True, force: bool = False, tail_mb: float = 4.0):
         self.pg = process_group
         self.force = force   # run the collectives even with a single rank (smoke-testing the RCCL path)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
         plist = [p for p in params if p.requires_grad]
         cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets: List[_Bucket] = []
+        groups: List[List[torch.nn.Parameter]] = []
         cur: List[torch.nn.Parameter] = []
         n = 0
         for p in reversed(plist):
             cur.append(p)
             n += p.numel()
             if n >= cap:
-                self.buckets.append(_Bucket(cur))
+                groups.append(cur)
                 cur, n = [], 0
         if cur:
-            self.buckets.append(_Bucket(cur))
+            groups.append(cur)
+        # The LAST bucket's all-reduce cannot overlap anything (it completes with the last gradient of backward), so it
+        # is kept small: the trailing parameters (the first layers of the network, registered first) are peeled off into
+        # a bucket of at most `tail_mb`; whatever else shared their bucket leaves as soon as it is complete.
+        tcap = int(tail_mb * 1024 * 1024 / 4)
+        if groups and tcap > 0 and sum(p.numel() for p in groups[-1]) > tcap and len(groups[-1]) > 1:
+            last = groups[-1]
+            k, acc = len(last), 0
+            while k > 1 and acc + last[k - 1].numel() <= tcap:
+                k -= 1
+                acc += last[k].numel()
+            if 0 < k < len(last):
+                groups[-1:] = [last[:k], last[k:]]
+        self.buckets: List[_Bucket] = [_Bucket(g) for g in groups]
         self._where = {}
         self._hooks = []
         for b in self.buckets:

@@ -24,11 +24,11 @@ for ev in prof.key_averages(group_by_stack_n=10):
 from collections import Counter
 cnt = Counter()
 for ev in prof.events():
-    if ev.name in ("aten::clone", "aten::copy_"):
+    if ev.name in ("aten::clone", "aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::div", "aten::neg", "aten::sum", "aten::zeros", "aten::zeros_like", "aten::ones_like"):
         chain, q = [], ev.cpu_parent
         while q is not None and len(chain) < 4:
             chain.append(q.name[:60])
             q = q.cpu_parent
         cnt[(ev.name, " <- ".join(chain))] += 1
-for (k, c), n in cnt.most_common(20):
+for (k, c), n in cnt.most_common(60):
     print(f"PARENT {k:12s} x{n:3d}  {c}")
