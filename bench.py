@@ -453,7 +453,7 @@ def main():
                       "overlap_fraction": ovl / tot if tot else None,
                       "overlap_note": "share of the all-reduce bytes issued from a gradient hook, i.e. while backward still ran "
                                       "(counted over the steps that ran Python: warm-up, capture, instrumented eager steps)",
-                      "buffer_broadcast_bytes_per_step": bufsync.bytes_sent // nst}
+                      "buffer_broadcast_bytes_per_step": bufsync.bytes_per_sync}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -204,6 +204,7 @@ class BufferSync:
         self.ibufs = [b for b in bufs if not b.is_floating_point()]
         self.flat: Optional[torch.Tensor] = None
         self.bytes_sent = 0
+        self.bytes_per_sync = sum(b.numel() * b.element_size() for b in bufs)
 
     def sync(self) -> None:
         """Call at the start of every step (before the forward pass)."""
