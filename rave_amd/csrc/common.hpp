@@ -53,5 +53,14 @@ __device__ __forceinline__ float rh_act_grad(float x, int act, float slope, floa
     return 1.f;
 }
 
+// max(a, b) as ONE v_max_f32.  fmaxf() on a value that came from memory costs two: the compiler first canonicalises the
+// operand (v_max x, x -- a loaded float may be a signalling NaN), 1 of the ~8.5 VALU instructions per converted sample of
+// the bf16x6 kernels.  NaN behaviour is the instruction's (IEEE maxNum), which is what fmaxf lowers to anyway.
+__device__ __forceinline__ float rh_max1(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 static inline int rh_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t rh_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

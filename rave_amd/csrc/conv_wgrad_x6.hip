@@ -58,7 +58,7 @@ __device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* ds
     unsigned h[3][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float x = fmaxf(v[i], v[i] * slope);
+        const float x = rh_max1(v[i], v[i] * slope);
         h[0][i] = __float_as_uint(x);
         const float r1 = x - __uint_as_float(h[0][i] & 0xffff0000u);
         h[1][i] = __float_as_uint(r1);
@@ -80,7 +80,12 @@ template <int TM, int WM, int WN, bool AV>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 64 * WN;
-    constexpr int A_UNITS = 6 * BM, B_UNITS = 6 * BN;                     // fragments of ONE k block
+    // fragments of ONE k block: [g][piece][rows], with 4 fragments of padding per g block.  The OCT = 4 lanes that convert
+    // the four octets of one row write to (k block, g) = (0,0), (0,1), (1,0), (1,1): without the padding those blocks are
+    // 3 * BM fragments = a multiple of 256 bytes apart and every ds_write_b128 was a 4-way bank conflict (PMC:
+    // SQ_LDS_BANK_CONFLICT 60 % of SQ_LDS_IDX_ACTIVE); with it the four lanes land 64 bytes apart.
+    constexpr int A_GS = 3 * BM + 4, B_GS = 3 * BN + 4;                   // g stride
+    constexpr int A_UNITS = 2 * A_GS, B_UNITS = 2 * B_GS;                 // k-block stride
     constexpr int OCT = 2 * kKS;                                          // 8-sample octets per row and step
     constexpr int NA = (OCT * BM + 255) / 256, NB = (OCT * BN + 255) / 256;   // tasks per thread and step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         const int u = tid + 256 * q;
         const int o = u % OCT, m = u / OCT;
         const bool ok = m < BM && m0 + m < p.M;
-        adst[q] = m < BM ? (o >> 1) * A_UNITS + (o & 1) * 3 * BM + m : -1;
+        adst[q] = m < BM ? (o >> 1) * A_UNITS + (o & 1) * A_GS + m : -1;
         apos[q] = 8 * o;
         aoff[q] = ok ? (unsigned)(((m0 + m) * p.r_row + 8 * o) * 4) : kOOB;
     }
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         const int o = u % OCT, col = u / OCT;
         const int cc = (n0 + col) / p.T, t = (n0 + col) - cc * p.T;
         const bool ok = col < BN && n0 + col < p.N;
-        bdst[q] = col < BN ? (o >> 1) * B_UNITS + (o & 1) * 3 * BN + col : -1;
+        bdst[q] = col < BN ? (o >> 1) * B_UNITS + (o & 1) * B_GS + col : -1;
         bp0[q] = 8 * o * p.is + (ok ? p.off[t] : 0);                  // position of sample 0 relative to n * is
         boff[q] = ok ? (unsigned)((cc * p.s_row + bp0[q]) * 4) : kOOB;
     }
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         convert();
     }
     __syncthreads();
-    const int arow = g * 3 * BM + wm * TM * 32 + j;
-    const int bcol = g * 3 * BN + wn * 64 + j;
+    const int arow = g * A_GS + wm * TM * 32 + j;
+    const int bcol = g * B_GS + wn * 64 + j;
     // one LDS stage: the next step's samples wait in registers while the matrix cores work on this step's fragments
     // (the other workgroup of the CU runs its MFMAs while this one converts)
     for (int s = 0; s < nst; ++s) {
@@ -321,7 +326,7 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
 template <int TM, int WM, bool AV>
 void go2(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
     auto kern = wgrad_x6_kernel<TM, WM, 4 / WM, AV>;
-    constexpr size_t lds = kKS * (6 * 32 * TM * WM + 6 * 64 * (4 / WM)) * 16;
+    constexpr size_t lds = kKS * (2 * (3 * 32 * TM * WM + 4) + 2 * (3 * 64 * (4 / WM) + 4)) * 16;
     static std::once_flag once;
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
         unsigned h[3][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float a = fmaxf(v[i], v[i] * slope);
+            const float a = rh_max1(v[i], v[i] * slope);
             h[0][i] = __float_as_uint(a);
             const float r1 = a - __uint_as_float(h[0][i] & 0xffff0000u);
             h[1][i] = __float_as_uint(r1);

@@ -9,7 +9,7 @@ i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
   ONLY="$L" timeout 300 rocprofv3 --kernel-trace --pmc $P -d $R/gpurun_out/pmc_$T$i -o p -- python $R/tools/bench_layers.py > $R/gpurun_out/pmc_$T$i.log 2>&1 < /dev/null
-  python $R/tools/pmc_summary.py $(find $R/gpurun_out/pmc_$T$i -name "*.db" | head -1) conv_x6 > $R/gpurun_out/pmc_$T$i.txt 2>&1
+  python $R/tools/pmc_summary.py $(find $R/gpurun_out/pmc_$T$i -name "*.db" | head -1) ${KPAT:-conv_x6} > $R/gpurun_out/pmc_$T$i.txt 2>&1
   rm -rf $R/gpurun_out/pmc_$T$i
 done
 cat $R/gpurun_out/pmc_${T}1.txt $R/gpurun_out/pmc_${T}2.txt
