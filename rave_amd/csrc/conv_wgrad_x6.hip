@@ -303,7 +303,14 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     p->minoff = w.minoff; p->maxoff = w.maxoff;
     for (int t = 0; t < w.T; ++t) p->off[t] = w.off[t];
     const int Mp = (w.M + 31) & ~31;
-    pl->tm = Mp % 96 == 0 ? 3 : (Mp % 64 == 0 ? 2 : 1);
+    // 96-row wave tiles (TM = 3: 216 VGPRs, two workgroups per CU) convert the least per MFMA, but 64-row ones (TM = 2:
+    // 158 VGPRs, 50 KB of LDS) fit THREE workgroups per CU, and a third set of phases to interleave is worth more wherever
+    // 128-row workgroup tiles divide the rows (measured per layer: C = 384 k = 3 76 -> 68 us, 384 -> 768 k = 8 111 -> 96,
+    // C = 768 91 -> 85; M = 192 loses a quarter of the tile and stays on TM = 3)
+    // -- and the reduction is long enough: pointwise layers (C = 384 / 768, k = 1) lose 5 ... 19 % with it
+    pl->tm = (Mp % 128 == 0 && Mp >= 256 && w.T > 1) ? 2 : (Mp % 96 == 0 ? 3 : (Mp % 64 == 0 ? 2 : 1));
+    static const int tm_env = [] { const char* e2 = getenv("RH_WGRAD_X6_TM"); return e2 ? atoi(e2) : 0; }();
+    if (tm_env >= 1 && tm_env <= 3) pl->tm = tm_env;
     pl->wm = Mp >= 64 * pl->tm ? 2 : 1;
     const int BM = 32 * pl->tm * pl->wm, BN = 64 * (4 / pl->wm);
     pl->rt = rh_cdiv(w.M, BM);
