@@ -287,7 +287,9 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     // (C = 96 at 4096 positions: one to three tiles, so K is cut into hundreds of slices whose partial tiles cost more
     // than the matrix work; the f32 kernel's 96-column tiles and LDS-DMA row segments win there).
     static const int force = [] { const char* e2 = getenv("RH_WGRAD_X6_ALL"); return e2 ? atoi(e2) : 0; }();
-    if (!force && w.M <= 96 && w.r_row > 1024) return false;
+    // (round 3: with conflict-free fragment writes and the cheaper conversion the 96-row layers moved over too -- C = 96 k = 3
+    // 115 -> 100 us, k = 1 59 -> 56; the 32-row output layer stays: 94 us on the f32 kernel against 120 here)
+    if (!force && w.M <= 64 && w.r_row > 1024) return false;
     const unsigned long long rb = 4ull * w.B * w.M * (unsigned long long)w.r_row;
     const unsigned long long sb = 4ull * w.B * w.C * (unsigned long long)w.s_row;
     if (rb >= 0x7fffffffull || sb >= 0x7fffffffull) return false;
