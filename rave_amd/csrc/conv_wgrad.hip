@@ -139,6 +139,36 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (w == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// Few slices of a large tensor (the wide layers: 1 ... 5 M weights x 2 ... 8 slices): one thread per FOUR consecutive elements,
+// 16-byte loads, all slices of a thread in flight (four running sums, fixed order -> deterministic).  The kernel above spends
+// a 256-thread workgroup on 64 elements, which is right for 27 k elements x 256 slices and wrong here (47 us for 75 MB).
+__global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                   long n4, int Z) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(part) + e;
+    f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int z = 0;
+    for (; z + 3 < Z; z += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 v = src[(long)(z + u) * n4];
+            s[u] += v;
+        }
+    }
+    for (; z < Z; ++z) s[0] += src[(long)z * n4];
+    reinterpret_cast<f32x4*>(out)[e] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+static void reduce_partials_go(const float* part, float* out, long n, int Z, hipStream_t stream) {
+    if (Z <= 16 && n >= (1l << 16) && (n & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0) {
+        const long n4 = n / 4;
+        hipLaunchKernelGGL(reduce_partials_vec4_kernel, dim3((unsigned)rh_cdiv64(n4, 256)), dim3(256), 0, stream, part, out, n4, Z);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 64)), dim3(256), 0, stream, part, out, n, Z);
+    }
+}
+
 // dbias[m] = sum_{b,h,w} dy * act'(y): grid (M, kBiasSlices) partial sums over interleaved 1024-element segments
 // of the (b, plane) index space, then an ordered pass over the slices (deterministic).
 constexpr int kBiasSlices = 64;
@@ -659,8 +689,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     else e = launch_w<2, 2, 2, 2>(p, w, stream);
     if (e) return e;
     if (w.Z > 1) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(nw, 64)), dim3(256), 0, stream,
-                           (const float*)ws, dw, nw, w.Z);
+        reduce_partials_go((const float*)ws, dw, nw, w.Z, stream);
         return rh_check_launch("conv1d_bwd_weight_reduce");
     }
     return RH_OK;
@@ -668,7 +697,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
 
 int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what) {
     if (n <= 0) return RH_OK;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 64)), dim3(256), 0, stream, part, out, n, Z);
+    reduce_partials_go(part, out, n, Z, stream);
     return rh_check_launch(what);
 }
 
