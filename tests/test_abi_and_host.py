@@ -78,7 +78,11 @@ def test_kernel_family_queries():
                       pad_left=3, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
     first = L.ConvDesc(batch=64, c_in=1, c_out=96, l_in=65536, l_out=16384, kernel=15, stride=4, dilation=1,
                        pad_left=7, transposed=0, groups=1, inner=1, in_valid=0, act=0, act_slope=0.0)
-    assert [fam(unit, 0), fam(unit, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(unit))] == [1, 1, 0]
+    out = L.ConvDesc(batch=32, c_in=96, c_out=32, l_in=4096, l_out=4096, kernel=7, stride=1, dilation=1,
+                     pad_left=3, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
+    assert [fam(unit, 0), fam(unit, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(unit))] == [1, 1, 1]
+    # <= 64 gradient rows on long sequences: the f32 MFMA weight-gradient kernel
+    assert [fam(out, 0), fam(out, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(out))] == [1, 1, 0]
     assert [fam(down, 0), fam(down, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(down))] == [1, 1, 1]
     assert [fam(first, 0), fam(first, 1), L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(first))] == [2, 2, 2]
     assert L.lib.rh_conv1d_workspace_bytes(C.byref(first)) > 0          # partial tiles of the fused weight + bias gradient
