@@ -319,7 +319,7 @@ def main():
         # ---- per-launch HIP-event timing of the conv kernels over instrumented replays of the step.  EVERY rank runs
         # these steps (they contain the gradient all-reduce); rank 0 reports.
         reps = 2
-        # (kernels are timed in ISOLATION: the weight-gradient / STFT side stream -- which overlaps launches in the timed
+        # (kernels are timed in ISOLATION: the weight-gradient side stream -- which overlaps launches in the timed
         # region above -- is switched off for these instrumented steps, so that an event pair brackets one kernel alone)
         side_env = os.environ.get("RH_BWD_SIDE_STREAM")
         os.environ["RH_BWD_SIDE_STREAM"] = "0"
