@@ -386,6 +386,24 @@ typedef struct rh_adam_item {
 int rh_adam_step_f32(const rh_adam_item* items, int32_t n_items, const float* lr, float beta1, float beta2, float eps,
                      float* step, float* aux, rh_stream_t stream);
 
+/* Feature-matching distance of the GAN phase (rave/model.py:359-372 over rave/core.py:236-252, norm "L1") on UNSPLIT
+ * discriminator feature maps: item i is a dense f32 tensor of 2 * half elements, the real half of the batch first;
+ * distance = sum_i w_i * (relative ? sum|r-f| / sum|r| : sum|r-f|)  (the host folds the 1 / count factors -- and for the
+ * non-relative form 1 / half -- into w_i).  `items` is a HOST array consumed during the call (<= 80 items).  fwd writes
+ * sums[2i] = sum|r-f|, sums[2i+1] = sum|r| and out[0]; bwd writes d distance / d feature * grad_out[0] into items[i].df
+ * (same layout as f).  workspace: rh_feature_matching_workspace_bytes(). */
+typedef struct rh_fm_item {
+    const float* f;
+    float* df;
+    int64_t half;
+    float w;
+} rh_fm_item;
+int64_t rh_feature_matching_workspace_bytes(const rh_fm_item* items, int32_t n_items);
+int rh_feature_matching_fwd_f32(const rh_fm_item* items, int32_t n_items, int32_t relative, void* workspace,
+                                int64_t workspace_bytes, float* sums, float* out, rh_stream_t stream);
+int rh_feature_matching_bwd_f32(const rh_fm_item* items, int32_t n_items, int32_t relative, const float* sums,
+                                const float* grad_out, rh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,11 @@ class AdamItem(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
+class FmItem(C.Structure):
+    """Mirror of ``rh_fm_item`` (include/rave_hip.h)."""
+    _fields_ = [("f", C.c_void_p), ("df", C.c_void_p), ("half", C.c_int64), ("w", C.c_float)]
+
+
 class Conv2dDesc(C.Structure):
     """Mirror of ``rh_conv2d_desc`` (include/rave_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
@@ -99,6 +104,9 @@ def _load() -> C.CDLL:
         "rh_stft_frame_bwd_f32": ([P, P, I64, I32, I32, I32, I32, P, P], C.c_int),
         "rh_stft_frame_bwd_acc_f32": ([P, P, I64, I32, I32, I32, I32, P, I32, P], C.c_int),
         "rh_spectral_total_f32": ([P, P, I32, P, P], C.c_int),
+        "rh_feature_matching_workspace_bytes": ([C.POINTER(FmItem), I32], I64),
+        "rh_feature_matching_fwd_f32": ([C.POINTER(FmItem), I32, I32, P, I64, P, P, P], C.c_int),
+        "rh_feature_matching_bwd_f32": ([C.POINTER(FmItem), I32, I32, P, P, P], C.c_int),
         "rh_adam_step_f32": ([C.POINTER(AdamItem), I32, P, F, F, F, P, P, P], C.c_int),
         "rh_set_kernel_events": ([P, P], C.c_int),
         "rh_kernel_events_used": ([], C.c_int),

@@ -183,6 +183,35 @@ class RAVE(nn.Module):
         z = self.encoder.reparametrize(z)[0]
         return self.decode(z)
 
+    def _fused_feature_matching(self, features):
+        """The feature-matching distance of rave/model.py:359-372 in one HIP pass over the unsplit feature maps
+        (rave_amd.ops.feature_matching) when the configured function is ``mean_difference(norm="L1"[, relative])`` on GPU
+        tensors; None -> the generic per-map formulation runs.  ``RH_FM_FUSED=0`` disables."""
+        import os
+        fun = self.feature_matching_fun
+        if os.environ.get("RH_FM_FUSED", "1") == "0" or not isinstance(fun, partial) or fun.func is not losses.mean_difference or fun.args:
+            return None
+        kw = dict(fun.keywords)
+        if kw.pop("norm", "L1") != "L1":
+            return None
+        relative = bool(kw.pop("relative", False))
+        if kw:
+            return None
+        maps, weights = [], []
+        for scale in features:
+            used = list(scale[self.num_skipped_features:])
+            if not used:
+                return None
+            for f in used:
+                if not (torch.is_tensor(f) and f.is_cuda and f.dtype == torch.float32 and f.shape[0] % 2 == 0 and f.numel() > 0):
+                    return None
+                maps.append(f)
+                weights.append(1.0 / (len(used) * len(features)))
+        if not maps or len(maps) > 80:
+            return None
+        from . import ops
+        return ops.feature_matching(maps, weights, relative)
+
     def split_features(self, features):
         """rave/model.py:276-286."""
         feature_real, feature_fake = [], []
@@ -262,15 +291,17 @@ class RAVE(nn.Module):
             feature_real, feature_fake = self.split_features(features)
             loss_dis = 0
             loss_adv = 0
+            fused_fm = self._fused_feature_matching(features)
             for scale_real, scale_fake in zip(feature_real, feature_fake):
-                current = sum(map(self.feature_matching_fun,
-                                  scale_real[self.num_skipped_features:],
-                                  scale_fake[self.num_skipped_features:])) / len(scale_real[self.num_skipped_features:])
-                feature_matching_distance = feature_matching_distance + current
+                if fused_fm is None:
+                    current = sum(map(self.feature_matching_fun,
+                                      scale_real[self.num_skipped_features:],
+                                      scale_fake[self.num_skipped_features:])) / len(scale_real[self.num_skipped_features:])
+                    feature_matching_distance = feature_matching_distance + current
                 _dis, _adv = self.gan_loss(scale_real[-1], scale_fake[-1])
                 loss_dis = loss_dis + _dis
                 loss_adv = loss_adv + _adv
-            feature_matching_distance = feature_matching_distance / len(feature_real)
+            feature_matching_distance = fused_fm if fused_fm is not None else feature_matching_distance / len(feature_real)
         else:
             loss_dis = torch.zeros((), device=x_raw.device, dtype=x_raw.dtype)     # (no host-to-device copy)
             loss_adv = torch.zeros((), device=x_raw.device, dtype=x_raw.dtype)

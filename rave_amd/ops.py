@@ -1157,6 +1157,79 @@ def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float) 
     return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), *windows)
 
 
+# --------------------------------------------------------------------------- feature matching (GAN phase)
+def _dense_batch_major(t: Tensor) -> bool:
+    """True if ``t``'s memory is one dense block in which dim 0 is outermost (any order of the other dims): its first
+    half along dim 0 is then the first half of the block -- the period discriminators hand out permuted views."""
+    if t.dim() < 1 or t.shape[0] % 2 or t.numel() == 0:
+        return False
+    if t.is_contiguous():
+        return True
+    n = t.numel()
+    if t.stride(0) * t.shape[0] != n:
+        return False
+    # the remaining dims must tile [0, stride(0)) exactly: sort by stride and check the products
+    dims = sorted(((t.stride(i), t.shape[i]) for i in range(1, t.dim()) if t.shape[i] > 1))
+    acc = 1
+    for st, sz in dims:
+        if st != acc:
+            return False
+        acc *= sz
+    return acc == t.stride(0)
+
+
+class _FeatureMatchingFn(torch.autograd.Function):
+    """sum_i w_i * mean_difference(real_i, fake_i, "L1"[, relative]) over UNSPLIT feature maps (real half of the batch first),
+    rh_feature_matching_{fwd,bwd}_f32: one pass per direction over every feature map instead of ~10 ATen passes."""
+
+    @staticmethod
+    def forward(ctx, relative: bool, weights, *feats):
+        fs = []
+        for f in feats:
+            f = _chk(f, "feature")
+            fs.append(f if _dense_batch_major(f) else f.contiguous())
+        n = len(fs)
+        dev = fs[0].device
+        arr = (L.FmItem * n)()
+        for i, (f, w) in enumerate(zip(fs, weights)):
+            half = f.numel() // 2
+            arr[i].f, arr[i].df, arr[i].half = f.data_ptr(), None, half
+            arr[i].w = float(w) if relative else float(w) / half
+        nbytes = L.lib.rh_feature_matching_workspace_bytes(arr, n)
+        if nbytes < 0:
+            raise RuntimeError("rave_amd feature_matching: too many feature maps for one call")
+        ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+        sums = torch.empty(n, 2, device=dev, dtype=torch.float32)
+        out = torch.empty((), device=dev, dtype=torch.float32)
+        L.check(L.lib.rh_feature_matching_fwd_f32(arr, n, int(relative), L.ptr(ws), nbytes, L.ptr(sums), L.ptr(out), L.stream()),
+                "feature_matching_fwd")
+        ctx.save_for_backward(sums, *fs)
+        ctx.meta = (bool(relative), [arr[i].w for i in range(n)])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        relative, ws = ctx.meta
+        sums = ctx.saved_tensors[0]
+        fs = ctx.saved_tensors[1:]
+        n = len(fs)
+        g = g.contiguous().reshape(1).float()
+        arr = (L.FmItem * n)()
+        dfs = []
+        for i, f in enumerate(fs):
+            df = torch.empty_like(f)           # same strides as f (dense): element k of the block is element k of f's block
+            dfs.append(df)
+            arr[i].f, arr[i].df, arr[i].half, arr[i].w = f.data_ptr(), df.data_ptr(), f.numel() // 2, ws[i]
+        L.check(L.lib.rh_feature_matching_bwd_f32(arr, n, int(relative), L.ptr(sums), L.ptr(g), L.stream()), "feature_matching_bwd")
+        return (None, None) + tuple(dfs)
+
+
+def feature_matching(features, weights, relative: bool) -> Tensor:
+    """``features``: unsplit discriminator feature maps (2B, ...), real half first; ``weights``: one factor per map (the
+    1 / (maps of its discriminator x discriminators) of rave/model.py:359-372)."""
+    return _FeatureMatchingFn.apply(bool(relative), tuple(float(w) for w in weights), *features)
+
+
 class _AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -462,3 +462,47 @@ def test_fused_adam_kernel_matches_torch_adam(dev):
     assert float(oa2.state[pa[0]]["step"]) == 7.0
     for a, b in zip(pa[:-1], pb[:-1]):
         assert rel_l2(a.detach(), b.detach()) < 2e-7
+
+
+@pytest.mark.parametrize("relative", [False, True])
+def test_fused_feature_matching_equals_the_per_map_formulation(dev, relative):
+    """rave_amd.ops.feature_matching (one HIP pass over the unsplit discriminator feature maps) against the reference's
+    formulation -- split, mean_difference(real, fake, "L1"[, relative]) per map, mean per discriminator, mean over the
+    discriminators (rave/model.py:359-372, rave/core.py:236-252) -- in f64: value and the gradient w.r.t. every map;
+    contiguous maps, the period discriminators' permuted views, odd sizes (scalar path), a score map of one channel."""
+    from rave_amd import ops as R, losses as LS
+    gen = torch.Generator().manual_seed(21)
+    shapes = [[(8, 16, 1000), (8, 32, 251), (8, 1, 63)], [(8, 16, 37, 3), (8, 24, 13, 3), (8, 1, 5, 3)], [(4, 7, 333)]]
+    feats = []
+    for si, scale in enumerate(shapes):
+        row = []
+        for shp in scale:
+            t = torch.randn(shp, generator=gen).to(dev)
+            if len(shp) == 4:                         # period-major storage handed out as a (B, C, H, W) view
+                b, c, h, w = shp
+                base = torch.randn(b, w, c, h, generator=gen).to(dev)
+                t = base.permute(0, 2, 3, 1)
+                assert not t.is_contiguous()
+            row.append(t.requires_grad_(True))
+        feats.append(row)
+    maps = [f for row in feats for f in row]
+    weights = [1.0 / (len(row) * len(feats)) for row in feats for _ in row]
+    d = R.feature_matching(maps, weights, relative)
+    grads = torch.autograd.grad(d, maps)
+    ref_maps = [f.detach().double().requires_grad_(True) for f in maps]
+    it = iter(ref_maps)
+    dr = 0
+    for row in feats:
+        cur = 0
+        for _ in row:
+            f = next(it)
+            r, k = torch.split(f, f.shape[0] // 2, 0)
+            cur = cur + LS.mean_difference(r, k, norm="L1", relative=relative)
+        dr = dr + cur / len(row)
+    dr = dr / len(feats)
+    gr = torch.autograd.grad(dr, ref_maps)
+    assert abs(float(d) - float(dr)) <= 2e-6 * abs(float(dr))
+    for a, b in zip(grads, gr):
+        assert a.shape == b.shape and rel_l2(a, b) < 2e-6
+    d2 = R.feature_matching(maps, weights, relative)          # deterministic
+    assert torch.equal(d, d2)
