@@ -1186,7 +1186,11 @@ class _FeatureMatchingFn(torch.autograd.Function):
     def forward(ctx, relative: bool, weights, *feats):
         fs = []
         for f in feats:
-            f = _chk(f, "feature")
+            if not f.is_cuda or f.dtype != torch.float32:
+                raise RuntimeError("rave_amd feature_matching: feature maps must be float32 tensors on the GPU")
+            # NOT _chk(): the period discriminators hand out permuted views of dense period-major tensors; they are used
+            # (and their gradients written) in their own memory order -- no copy, and the gradient goes back through the
+            # view without one
             fs.append(f if _dense_batch_major(f) else f.contiguous())
         n = len(fs)
         dev = fs[0].device
