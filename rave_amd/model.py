@@ -207,10 +207,14 @@ class RAVE(nn.Module):
                     return None
                 maps.append(f)
                 weights.append(1.0 / (len(used) * len(features)))
-        if not maps or len(maps) > 80:
+        if not maps:
             return None
         from . import ops
-        return ops.feature_matching(maps, weights, relative)
+        total = None
+        for i in range(0, len(maps), 80):          # one kernel-argument table holds 80 maps (descript: > 100 per step)
+            part = ops.feature_matching(maps[i:i + 80], weights[i:i + 80], relative)
+            total = part if total is None else total + part
+        return total
 
     def split_features(self, features):
         """rave/model.py:276-286."""
