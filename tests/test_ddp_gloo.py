@@ -217,3 +217,24 @@ def test_gradients_live_in_the_buckets_and_in_place_writers_skip_the_pack(tmp_pa
     for (a, _), (b, _) in [(out[0], out[1])]:
         for ra, rb in zip(a, b):
             assert all(torch.equal(u, v) for u, v in zip(ra[:3], rb[:3]))
+
+
+def test_last_bucket_is_cut_short():
+    """Bucket layout of GradReducer (no process group needed): reverse registration order, ~bucket_mb per bucket, and the
+    LAST bucket -- whose all-reduce completes with the last gradient of backward and overlaps nothing -- at most tail_mb."""
+    from rave_amd.ddp import GradReducer
+    sizes = [10, 20, 300_000, 5, 4_000_000, 9_000_000, 100, 2_000_000, 50]
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    red = GradReducer(ps, bucket_mb=32.0, tail_mb=4.0)
+    flat_order = [p for b in red.buckets for p in b.params]
+    assert [p.numel() for p in flat_order] == sizes[::-1]                    # reverse registration order, nothing lost
+    mib = [b.numel * 4 / 2 ** 20 for b in red.buckets]
+    assert len(red.buckets) == 3 and mib[-1] <= 4.0 and mib[0] >= 32.0
+    assert [len(b.params) for b in red.buckets] == [4, 1, 4]
+    # a single small bucket is left alone; tail_mb = 0 disables the cut
+    assert len(GradReducer(ps[:2], bucket_mb=8.0).buckets) == 1
+    assert len(GradReducer(ps, bucket_mb=32.0, tail_mb=0.0).buckets) == 2
+    for p in ps:                                                             # every parameter got its view
+        v, fresh = p._rh_grad_slot
+        assert v.shape == p.shape and fresh is False
+    red.remove()
