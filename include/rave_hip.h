@@ -404,6 +404,15 @@ int rh_feature_matching_fwd_f32(const rh_fm_item* items, int32_t n_items, int32_
 int rh_feature_matching_bwd_f32(const rh_fm_item* items, int32_t n_items, int32_t relative, const float* sums,
                                 const float* grad_out, rh_stream_t stream);
 
+/* VariationalEncoder.reparametrize (rave/blocks.py:727-745): z (batch, 2c, l) = [mean | scale] along dim 1, eps (batch, c, l)
+ * the noise draw;  std = softplus(scale) + 1e-4,  zs = eps * std + mean,
+ * kl[0] = (mean^2 + std^2 - log(std^2) - 1).sum(1).mean().  bwd: dz from dzs (may be NULL) and the scalar dkl (may be NULL). */
+int64_t rh_reparam_workspace_bytes(void);
+int rh_reparam_fwd_f32(const float* z, const float* eps, int32_t batch, int32_t c, int32_t l, float* zs, float* kl,
+                       void* workspace, int64_t workspace_bytes, rh_stream_t stream);
+int rh_reparam_bwd_f32(const float* z, const float* eps, const float* dzs, const float* dkl, int32_t batch, int32_t c,
+                       int32_t l, float* dz, rh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,9 @@ def _load() -> C.CDLL:
         "rh_feature_matching_workspace_bytes": ([C.POINTER(FmItem), I32], I64),
         "rh_feature_matching_fwd_f32": ([C.POINTER(FmItem), I32, I32, P, I64, P, P, P], C.c_int),
         "rh_feature_matching_bwd_f32": ([C.POINTER(FmItem), I32, I32, P, P, P], C.c_int),
+        "rh_reparam_workspace_bytes": ([], I64),
+        "rh_reparam_fwd_f32": ([P, P, I32, I32, I32, P, P, P, I64, P], C.c_int),
+        "rh_reparam_bwd_f32": ([P, P, P, P, I32, I32, I32, P, P], C.c_int),
         "rh_adam_step_f32": ([C.POINTER(AdamItem), I32, P, F, F, F, P, P, P], C.c_int),
         "rh_set_kernel_events": ([P, P], C.c_int),
         "rh_kernel_events_used": ([], C.c_int),

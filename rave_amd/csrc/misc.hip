@@ -559,3 +559,84 @@ extern "C" int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, 
     hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, l_in, l_out, total);
     return rh_check_launch("avgpool2_bwd");
 }
+
+// ---- VariationalEncoder.reparametrize (rave/blocks.py:727-745) in two launches + one for the gradient --------------------
+//   mean, scale = z.chunk(2, 1);  std = softplus(scale) + 1e-4;  zs = eps * std + mean
+//   kl = (mean^2 + std^2 - log(std^2) - 1).sum(1).mean()  = total / (B * L)
+// (~12 ATen kernels forward and ~20 backward on a 0.5 MB tensor: launch-bound plumbing between encoder and decoder)
+namespace {
+
+constexpr int kRpBlocks = 64;
+
+__device__ __forceinline__ float softplus_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ z, const float* __restrict__ eps, int C, int L,
+                                                          long n, float* __restrict__ zs, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long CL = (long)C * L;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long b = e / CL, r = e - b * CL;
+        const float mean = z[b * 2 * CL + r], scale = z[b * 2 * CL + CL + r];
+        // every operation rounded separately, in ATen's order (no fused multiply-add): zs is then bit-identical to the
+        // ATen chain it replaces -- the activations downstream are gated on its sign pattern
+        const float sd = __fadd_rn(softplus_(scale), 1e-4f);
+        const float var = __fmul_rn(sd, sd);
+        zs[e] = __fadd_rn(__fmul_rn(eps[e], sd), mean);
+        s += __fsub_rn(__fsub_rn(__fadd_rn(__fmul_rn(mean, mean), var), logf(var)), 1.f);
+    }
+    const float t = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ void reparam_finalize_kernel(const float* __restrict__ part, int nblocks, float inv, float* __restrict__ kl) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nblocks; ++i) s += part[i];
+        kl[0] = s * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restrict__ z, const float* __restrict__ eps,
+                                                          const float* __restrict__ dzs, const float* __restrict__ dkl, int C, int L,
+                                                          long n, float inv, float* __restrict__ dz) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const long CL = (long)C * L;
+    const long b = e / CL, r = e - b * CL;
+    const float mean = z[b * 2 * CL + r], scale = z[b * 2 * CL + CL + r];
+    const float sd = __fadd_rn(softplus_(scale), 1e-4f);
+    const float g = dkl ? dkl[0] * inv : 0.f;
+    const float up = dzs ? dzs[e] : 0.f;
+    const float dmean = up + g * 2.f * mean;
+    const float dsd = up * eps[e] + g * (2.f * sd - 2.f / sd);
+    const float sig = scale > 20.f ? 1.f : 1.f / (1.f + expf(-scale));       // d softplus (threshold 20 as torch)
+    dz[b * 2 * CL + r] = dmean;
+    dz[b * 2 * CL + CL + r] = dsd * sig;
+}
+
+}  // namespace
+
+extern "C" int64_t rh_reparam_workspace_bytes(void) { return (int64_t)kRpBlocks * (int64_t)sizeof(float); }
+
+extern "C" int rh_reparam_fwd_f32(const float* z, const float* eps, int32_t batch, int32_t c, int32_t l, float* zs, float* kl,
+                                  void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    RH_REQUIRE(z && eps && zs && kl && workspace && workspace_bytes >= rh_reparam_workspace_bytes(), RH_ERR_INVALID, "reparam_fwd: bad arguments");
+    const long n = (long)batch * c * l;
+    RH_REQUIRE(n > 0, RH_ERR_INVALID, "reparam_fwd: empty tensor");
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(kRpBlocks), dim3(256), 0, (hipStream_t)stream, z, eps, c, l, n, zs, (float*)workspace);
+    if (int e = rh_check_launch("reparam_fwd")) return e;
+    hipLaunchKernelGGL(reparam_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, kRpBlocks,
+                       (float)(1.0 / ((double)batch * l)), kl);
+    return rh_check_launch("reparam_finalize");
+}
+
+extern "C" int rh_reparam_bwd_f32(const float* z, const float* eps, const float* dzs, const float* dkl, int32_t batch, int32_t c,
+                                  int32_t l, float* dz, rh_stream_t stream) {
+    RH_REQUIRE(z && eps && dz, RH_ERR_INVALID, "reparam_bwd: null pointer");
+    const long n = (long)batch * c * l;
+    if (n <= 0) return RH_OK;
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, z, eps, dzs, dkl, c, l, n,
+                       (float)(1.0 / ((double)batch * l)), dz);
+    return rh_check_launch("reparam_bwd");
+}

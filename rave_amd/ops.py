@@ -1157,6 +1157,44 @@ def multiscale_stft_distance(x: Tensor, y: Tensor, windows, scales, eps: float) 
     return _MultiScaleStftDistanceFn.apply(x, y, float(eps), tuple(int(s) for s in scales), *windows)
 
 
+# --------------------------------------------------------------------------- reparametrisation + KL
+class _ReparamFn(torch.autograd.Function):
+    """VariationalEncoder.reparametrize (rave/blocks.py:727-745) on rh_reparam_{fwd,bwd}_f32: (zs, kl) from z = [mean | scale]
+    and the noise draw eps."""
+
+    @staticmethod
+    def forward(ctx, z, eps):
+        z = _chk(z, "z"); eps = _chk(eps, "eps")
+        b, c2, l = z.shape
+        c = c2 // 2
+        if c2 % 2 or tuple(eps.shape) != (b, c, l):
+            raise RuntimeError("rave_amd reparametrize: z must be (B, 2C, L) and eps (B, C, L)")
+        zs = torch.empty(b, c, l, device=z.device, dtype=torch.float32)
+        kl = torch.empty((), device=z.device, dtype=torch.float32)
+        nbytes = L.lib.rh_reparam_workspace_bytes()
+        ws = torch.empty(nbytes // 4, device=z.device, dtype=torch.float32)
+        L.check(L.lib.rh_reparam_fwd_f32(L.ptr(z), L.ptr(eps), b, c, l, L.ptr(zs), L.ptr(kl), L.ptr(ws), nbytes, L.stream()),
+                "reparam_fwd")
+        ctx.save_for_backward(z, eps)
+        return zs, kl
+
+    @staticmethod
+    def backward(ctx, dzs, dkl):
+        z, eps = ctx.saved_tensors
+        b, c2, l = z.shape
+        dzs = _chk(dzs, "dzs")
+        dkl = None if dkl is None else dkl.contiguous().reshape(1).float()
+        dz = torch.empty_like(z)
+        L.check(L.lib.rh_reparam_bwd_f32(L.ptr(z), L.ptr(eps), L.ptr(dzs), L.ptr(dkl), b, c2 // 2, l, L.ptr(dz), L.stream()),
+                "reparam_bwd")
+        return dz, None
+
+
+def reparametrize(z: Tensor, eps: Tensor):
+    """(eps * std + mean, KL) of rave/blocks.py:727-745 for z = [mean | scale] (B, 2C, L)."""
+    return _ReparamFn.apply(z, eps)
+
+
 # --------------------------------------------------------------------------- feature matching (GAN phase)
 def _dense_batch_major(t: Tensor) -> bool:
     """True if ``t``'s memory is one dense block in which dim 0 is outermost (any order of the other dims): its first

@@ -506,3 +506,38 @@ def test_fused_feature_matching_equals_the_per_map_formulation(dev, relative):
         assert a.shape == b.shape and rel_l2(a, b) < 2e-6
     d2 = R.feature_matching(maps, weights, relative)          # deterministic
     assert torch.equal(d, d2)
+
+
+def test_fused_reparametrize_equals_the_torch_formulation(dev):
+    """rave_amd.ops.reparametrize (rh_reparam_*_f32) against VariationalEncoder.reparametrize's torch ops
+    (rave/blocks.py:727-745) in f64: zs, KL and the gradient w.r.t. z through both outputs; softplus beyond its
+    threshold of 20 included."""
+    from rave_amd import blocks as B
+    gen = torch.Generator().manual_seed(3)
+    z = (3.0 * torch.randn(5, 2 * 24, 37, generator=gen)).to(dev)
+    z[0, 24:, :5] = 25.0                                   # softplus(x) = x above 20
+    z[1, 24:, :5] = -30.0                                  # std -> 1e-4
+    eps = torch.randn(5, 24, 37, generator=gen).to(dev)
+    enc = B.VariationalEncoder.__new__(B.VariationalEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.beta = 1.0
+    za = z.clone().requires_grad_(True)
+    os.environ["RH_REPARAM_FUSED"] = "1"                   # opt-in path
+    try:
+        zs, kl = enc.reparametrize(za, eps)
+    finally:
+        os.environ.pop("RH_REPARAM_FUSED", None)
+    w = torch.randn(zs.shape, generator=gen).to(dev)
+    ((zs * w).sum() + 0.7 * kl).backward()
+    zb = z.double().clone().requires_grad_(True)
+    mean, scale = zb.chunk(2, 1)
+    std = torch.nn.functional.softplus(scale) + 1e-4
+    var = std * std
+    zr = eps.double() * std + mean
+    klr = (mean * mean + var - torch.log(var) - 1).sum(1).mean()
+    ((zr * w.double()).sum() + 0.7 * klr).backward()
+    assert rel_l2(zs.detach(), zr.detach()) < 1e-6
+    assert abs(float(kl) - float(klr)) <= 2e-6 * abs(float(klr))
+    assert rel_l2(za.grad, zb.grad) < 2e-6
+    zs2, kl2 = enc.reparametrize(z, eps)                   # default: the ATen formulation of the same module
+    assert rel_l2(zs.detach(), zs2) < 1e-6 and abs(float(kl) - float(kl2)) <= 1e-5 * abs(float(kl2))
