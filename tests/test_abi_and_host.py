@@ -361,3 +361,21 @@ def test_gin_overlay_builds_the_unmodified_rave_on_the_drop_in_modules():
     drop = lambda sd: {k: v for k, v in sd.items() if not k.endswith(("paddings.0.pad", ".pad"))}
     assert drop(hip["sd"]) == drop(ref["sd"])
     assert all(s.startswith("dataset.") for s in hip["skipped"])       # only rave.dataset (udls / lmdb) is out of reach
+
+
+def test_dense_batch_major_layout_check():
+    """Host logic of the fused feature-matching op (rave_amd.ops._dense_batch_major): which feature-map layouts can be used
+    in their own memory order -- dim 0 outermost over one dense block, any order of the other dims."""
+    import torch
+    from rave_amd.ops import _dense_batch_major as ok
+    b, p, c, h = 8, 7, 12, 5
+    base = torch.zeros(b * p, c, h)
+    assert ok(base.view(b, p * c * h)) and ok(base.view(b, p, c, h))
+    view = base.view(b, p, c, h).permute(0, 2, 3, 1)            # what the period discriminators hand out
+    assert not view.is_contiguous() and ok(view)
+    assert torch.empty_like(view).stride() == view.stride()     # the gradient buffer takes the same memory order
+    assert not ok(base.view(b, p, c, h).permute(1, 0, 2, 3))    # batch not outermost
+    assert not ok(base.view(b, p, c, h)[:, :, :, :3])           # not dense
+    assert not ok(base.view(b, p, c, h)[:, :3])                 # gaps between batch items
+    assert not ok(torch.zeros(7, 4))                            # odd batch: no real / fake halves
+    assert ok(torch.zeros(2, 1, 1, 9).permute(0, 3, 1, 2))      # size-1 dims do not matter
