@@ -351,6 +351,9 @@ int rh_spectral_total_f32(const float* sums, const float* inv_n, int32_t n_scale
  * rh_spectral_distance_fwd_f32 (n_complex = rows * (t_len / hop + 1) * (n_fft / 2 + 1)); the backward recomputes the
  * spectra, and writes (accumulate = 0) or adds (!= 0) d distance / d x and / d y (either may be NULL) times grad_out[0]. */
 int rh_stft_loss_supported(int32_t n_fft, int32_t hop, int32_t t_len, int64_t rows);
+/* diagnostics: out6 = {frames per forward workgroup, forward workgroups per row, hop blocks per backward workgroup, backward
+ * workgroups per row, hop blocks of the last backward workgroup, dynamic LDS bytes of the backward launch} */
+int rh_stft_loss_plan_info(int32_t n_fft, int32_t t_len, int64_t rows, int64_t* out6);
 int64_t rh_stft_loss_workspace_bytes(int32_t n_fft, int32_t t_len, int64_t rows);
 int rh_stft_loss_fwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,
                          int32_t t_len, int32_t n_fft, float eps, float* sums, void* workspace, int64_t workspace_bytes,

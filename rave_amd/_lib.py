@@ -117,6 +117,7 @@ def _load() -> C.CDLL:
         "rh_event_destroy": ([P], C.c_int),
         "rh_event_elapsed_ms": ([P, P, C.POINTER(C.c_float)], C.c_int),
         "rh_stft_loss_supported": ([I32, I32, I32, I64], C.c_int),
+        "rh_stft_loss_plan_info": ([I32, I32, I64, C.POINTER(I64)], C.c_int),
         "rh_stft_loss_workspace_bytes": ([I32, I32, I64], I64),
         "rh_stft_loss_fwd_f32": ([P, P, P, P, I64, I32, I32, F, P, P, I64, P], C.c_int),
         "rh_stft_loss_bwd_f32": ([P, P, P, P, I64, I32, I32, F, P, P, P, P, I32, P], C.c_int),

@@ -535,6 +535,23 @@ extern "C" int rh_stft_loss_supported(int32_t n_fft, int32_t hop, int32_t t_len,
     return shape_ok(n_fft, hop, t_len, rows) ? 1 : 0;
 }
 
+// Diagnostics / tests (no GPU needed): out = {frames per forward workgroup, forward workgroups per row, hop blocks per backward
+// workgroup, backward workgroups per row, hop blocks of the LAST backward workgroup, dynamic LDS bytes of the backward launch}
+extern "C" int rh_stft_loss_plan_info(int32_t n_fft, int32_t t_len, int64_t rows, int64_t* out6) {
+    RH_REQUIRE(out6, RH_ERR_INVALID, "stft_loss_plan_info: null output");
+    RH_REQUIRE(shape_ok(n_fft, n_fft / 4, t_len, rows), RH_ERR_UNSUPPORTED, "stft_loss_plan_info: unsupported geometry");
+    const int H = n_fft / 4, nf = t_len / H + 1;
+    const int fpw = fpw_of(n_fft, nf, rows);
+    const int n_blocks = (t_len + n_fft + H - 1) / H;
+    const int cb = choose_cb(n_fft, n_blocks, rows);
+    const int nch = chunks_of(n_blocks, cb);
+    const int last = n_blocks - (nch - 1) * cb;
+    const int G = 256 / (n_fft / 8);
+    out6[0] = fpw; out6[1] = (nf + fpw - 1) / fpw; out6[2] = cb; out6[3] = nch; out6[4] = last;
+    out6[5] = (int64_t)G * (n_fft + n_fft / 8) * 8 + 2l * (last > cb ? last : cb) * H * 4;
+    return RH_OK;
+}
+
 extern "C" int64_t rh_stft_loss_workspace_bytes(int32_t n_fft, int32_t t_len, int64_t rows) {
     if (!shape_ok(n_fft, n_fft / 4, t_len, rows)) return 0;
     const int nf = t_len / (n_fft / 4) + 1;

@@ -379,3 +379,33 @@ def test_dense_batch_major_layout_check():
     assert not ok(base.view(b, p, c, h)[:, :3])                 # gaps between batch items
     assert not ok(torch.zeros(7, 4))                            # odd batch: no real / fake halves
     assert ok(torch.zeros(2, 1, 1, 9).permute(0, 3, 1, 2))      # size-1 dims do not matter
+
+
+def test_stft_loss_launch_plans_cover_every_geometry():
+    """Host side of the in-kernel STFT distance (stft_loss.hip) over many (n_fft, length, rows): the forward workgroups cover
+    every frame; the backward workgroups tile the padded row in whole hop blocks, the first one owns the left margin and
+    what it folds onto (> n_fft samples), the last one the right margin (>= 6 blocks), and the LDS image fits."""
+    import ctypes as C
+    from rave_amd import _lib as L
+    out = (C.c_int64 * 6)()
+    checked = 0
+    for n_fft in (128, 256, 512, 1024, 2048):
+        hop = n_fft // 4
+        for t_len in (n_fft // 2 + 1, n_fft, 1100, 4096, 5000, 65536, 65536 + 4, 131072 + hop - 1, 1 << 20):
+            for rows in (1, 2, 32, 512, 4096):
+                if not L.lib.rh_stft_loss_supported(n_fft, hop, t_len, rows):
+                    assert t_len <= n_fft // 2
+                    continue
+                assert L.lib.rh_stft_loss_plan_info(n_fft, t_len, rows, out) == 0
+                fpw, fwd_wgs, cb, nch, last, lds = list(out)
+                nf = t_len // hop + 1
+                n_blocks = (t_len + n_fft + hop - 1) // hop
+                g = 256 // (n_fft // 8)
+                assert fpw % g == 0 and fwd_wgs * fpw >= nf > (fwd_wgs - 1) * fpw
+                assert (nch - 1) * cb + last == n_blocks and last >= 6 and (nch == 1 or cb >= 6)
+                assert min(cb, n_blocks) * hop > n_fft                 # first workgroup: left margin + its fold targets
+                assert lds <= 160 * 1024
+                assert L.lib.rh_stft_loss_workspace_bytes(n_fft, t_len, rows) == rows * fwd_wgs * 12
+                checked += 1
+    assert checked > 150
+    assert L.lib.rh_stft_loss_plan_info(2048, 1024, 4, out) < 0       # reflect padding needs t > n_fft / 2
