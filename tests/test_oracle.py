@@ -391,3 +391,29 @@ def test_oracle_reproduces_the_full_width_reference_golden(golden_dir):
     for k, gref in g["grads"].items():
         got = _sub(leaves[k].grad, g["grad_step"], g["grad_keep"])
         assert rel_l2(got, gref) < 1e-5, (k, rel_l2(got, gref))
+
+
+def test_stft_loss_algorithm_restatement_vs_torch_stft():
+    """oracle/stft_loss_algorithm.py (the algebra of stft_loss.hip: packed frame pairs, Stockham passes with the kernel's
+    index arithmetic, Hermitian gradient operand, swap-FFT-swap inverse, overlap-add, margin folds) against torch.stft +
+    autograd in f64, the reference's formulation (rave/core.py:269-344)."""
+    import numpy as np
+    import stft_loss_algorithm as A
+    rng = np.random.default_rng(0)
+    for n in (128, 256, 512, 1024, 2048):                    # the Stockham passes are the DFT
+        z = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        assert np.abs(A.stockham_fft(z) - np.fft.fft(z)).max() < 1e-10
+    eps = 1e-7
+    for n, t, rows, fft in ((128, 1000, 3, A.stockham_fft), (256, 777, 2, np.fft.fft), (512, 4100, 2, np.fft.fft)):
+        win = torch.hann_window(n, dtype=torch.float64)
+        win = win / win.pow(2).sum().sqrt()
+        x = torch.randn(rows, t, dtype=torch.float64, requires_grad=True)
+        y = torch.randn(rows, t, dtype=torch.float64, requires_grad=True)
+        sx = torch.stft(x, n, n // 4, n, win, center=True, pad_mode="reflect", return_complex=True).abs()
+        sy = torch.stft(y, n, n // 4, n, win, center=True, pad_mode="reflect", return_complex=True).abs()
+        d = ((sx - sy) ** 2).mean() / (sx ** 2).mean() + (torch.log(sx + eps) - torch.log(sy + eps)).abs().mean()
+        d.backward()
+        dist, dx, dy = A.distance_and_gradients(x.detach().numpy(), y.detach().numpy(), win.numpy(), eps, fft)
+        assert abs(dist - float(d)) <= 1e-12 * abs(float(d))
+        assert np.abs(dx - x.grad.numpy()).max() <= 1e-10 * np.abs(x.grad.numpy()).max()
+        assert np.abs(dy - y.grad.numpy()).max() <= 1e-10 * np.abs(y.grad.numpy()).max()
