@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r3; mkdir -p $O
 PARTS=${PARTS:-all}
 has() { [ "$PARTS" = all ] || echo " $PARTS " | grep -q " $1 "; }
-if has probes; then
+if has probes; then      # (binaries: bash tools/probe/build.sh in the build container)
   timeout 120 tools/probe/_var/mfma_clock > $O/probe_mfma_clock.txt 2>&1
   timeout 60 tools/probe/_var/tr_read > $O/probe_tr_read.txt 2>&1
 fi
