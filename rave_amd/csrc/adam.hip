@@ -95,10 +95,12 @@ extern "C" int rh_adam_step_f32(const rh_adam_item* items, int32_t n_items, cons
     RH_REQUIRE(n_items == 0 || items, RH_ERR_INVALID, "adam_step: null table");
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, aux, (double)beta1, (double)beta2);
     if (int e = rh_check_launch("adam_tick")) return e;
-    for (int i0 = 0; i0 < n_items; i0 += kAdamItems) {
+    // `i` is the consumed index: empty tensors are skipped without taking a table slot, so a chunk may span more than
+    // kAdamItems items -- the next chunk continues where this one stopped (never re-processing an item)
+    for (int i = 0; i < n_items;) {
         AdamTable tb;
         int cnt = 0, blk = 0;
-        for (int i = i0; i < n_items && cnt < kAdamItems; ++i) {
+        for (; i < n_items && cnt < kAdamItems; ++i) {
             const rh_adam_item& it = items[i];
             RH_REQUIRE(it.p && it.g && it.m && it.v && it.n >= 0 && it.n < 0x7fffffffl, RH_ERR_INVALID, "adam_step: bad item %d", i);
             if (it.n == 0) continue;

@@ -465,7 +465,8 @@ extern "C" int rh_stft_frame_fwd_f32(const float* x, const float* window, int64_
     RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_fwd: bad geometry");
     const long total = rows * (long)n_frames * n_fft;
     if (total <= 0) return RH_OK;
-    const bool vec = (n_fft & 3) == 0 && (hop & 3) == 0 && (t_len & 3) == 0 && total / 4 < 0xffffffffl &&
+    // (the 16-byte paths index window / frames at q = p0 + n_fft / 2: n_fft / 2 must be a multiple of 4 too)
+    const bool vec = (n_fft & 7) == 0 && (hop & 3) == 0 && (t_len & 3) == 0 && total / 4 < 0xffffffffl &&
                      (((uintptr_t)x | (uintptr_t)window | (uintptr_t)frames) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(stft_frame_fwd4_kernel, dim3(blocks_for(total / 4)), dim3(256), 0, (hipStream_t)stream, x, window, t_len,
@@ -483,7 +484,8 @@ extern "C" int rh_stft_frame_bwd_acc_f32(const float* dframes, const float* wind
     RH_REQUIRE(n_fft > 0 && hop > 0 && t_len > n_fft / 2 && n_frames > 0, RH_ERR_INVALID, "stft_frame_bwd: bad geometry");
     const long total = rows * (long)t_len;
     if (total <= 0) return RH_OK;
-    const bool vec = (n_fft & 3) == 0 && (hop & 3) == 0 && (t_len & 3) == 0 && total / 4 < 0xffffffffl &&
+    // (the 16-byte paths index window / frames at q = p0 + n_fft / 2: n_fft / 2 must be a multiple of 4 too)
+    const bool vec = (n_fft & 7) == 0 && (hop & 3) == 0 && (t_len & 3) == 0 && total / 4 < 0xffffffffl &&
                      (((uintptr_t)dframes | (uintptr_t)window | (uintptr_t)dx) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(stft_frame_bwd4_kernel, dim3(blocks_for(total / 4)), dim3(256), 0, (hipStream_t)stream, dframes, window,

@@ -95,7 +95,7 @@ class GradReducer:
                 b.index[p] = i
                 # [view, fresh]: the conv operators' backward writes the gradient into `view` and returns it while
                 # `fresh` (set by begin(), cleared by the first writer of the step) -- rave_amd.ops.grad_slot
-                p._rh_grad_slot = [v, False]
+                p._rh_grad_slot = [v, False, False]      # [view, fresh, reducer active for this step]
                 self._where[p] = b
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         backend = dist.get_backend(process_group) if dist.is_initialized() else ""
@@ -117,6 +117,7 @@ class GradReducer:
             b.launched = False
             for p in b.params:
                 p._rh_grad_slot[1] = self.enabled and p.grad is None
+                p._rh_grad_slot[2] = self.enabled
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if not self.enabled:
@@ -173,6 +174,7 @@ class GradReducer:
         for b in self.buckets:
             for p in b.params:
                 p._rh_grad_slot[1] = False
+                p._rh_grad_slot[2] = False
         self.enabled = False
 
     def remove(self) -> None:

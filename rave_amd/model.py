@@ -503,6 +503,16 @@ def _clone_opt(opt):
 
 
 def _restore_opt(opt, saved):
+    # two passes: state tensors may be SHARED between parameters (rave_amd.optim.FusedAdam keeps one step counter per group,
+    # aliased into every state[p]["step"]) -- first reset whatever the warm-up iterations created, then restore the saved
+    # values, so that a restored counter is never zeroed afterwards through an alias (dict order must not decide)
+    for p in list(opt.state.keys()):
+        if id(p) not in saved:
+            # state created by the warm-up iterations: keep the tensors (a state created INSIDE the capture would be
+            # re-initialised by every replay) but reset them to the freshly-initialised values (all zero)
+            for k, v in opt.state[p].items():
+                if torch.is_tensor(v):
+                    v.zero_()
     for p in list(opt.state.keys()):
         if id(p) in saved:
             for k, v in saved[id(p)].items():
@@ -510,12 +520,6 @@ def _restore_opt(opt, saved):
                     opt.state[p][k].copy_(v)
                 else:
                     opt.state[p][k] = v
-        else:
-            # state created by the warm-up iterations: keep the tensors (a state created INSIDE the capture would be
-            # re-initialised by every replay) but reset them to the freshly-initialised values (all zero)
-            for k, v in opt.state[p].items():
-                if torch.is_tensor(v):
-                    v.zero_()
 
 
 V2_DILATIONS = [[1, 3, 9], [1, 3, 9], [1, 3, 9], [1, 3]]

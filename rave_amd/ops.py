@@ -148,6 +148,31 @@ def _shadow(kind: str, d, run, outs) -> None:
             _SHADOW.append((kind, key, _rel(o, o2)))
 
 
+# ---- optional gate log (parity tests): every conv launch in forward order with the parameters it carries and -- where a
+# LeakyReLU is fused into its input staging -- the pre-activation tensor itself.  A LeakyReLU gate is the one discontinuity
+# of the hot path's backward: a pre-activation within rounding of zero takes the other slope in another fp32 evaluation and
+# changes that element's gradient 5x.  The tests COUNT such flips between two evaluations (sign masks of the logged tensors)
+# and require every parameter gradient outside the tight bound to lie upstream (in the backward sense) of at least one.
+_GATE_LOG = None
+
+
+def gate_log_begin() -> None:
+    global _GATE_LOG
+    _GATE_LOG = []
+
+
+def gate_log_end():
+    """[(ids of the parameters of the launch, pre-activation tensor or None)] in forward launch order."""
+    global _GATE_LOG
+    rec, _GATE_LOG = _GATE_LOG, None
+    return rec
+
+
+def _log_gate(params, x, act: int) -> None:
+    if _GATE_LOG is not None:
+        _GATE_LOG.append((tuple(id(p) for p in params if p is not None), x.detach() if act == ACT_LEAKY else None))
+
+
 def _conv_cost(d: "L.ConvDesc"):
     """Algorithmic FLOPs and bytes of one conv launch (SURVEY.md section 8d rule: input once, output
     once, weights once, fp32; activation / padding / residual count zero)."""
@@ -324,12 +349,21 @@ def _note_use(ctx, *params) -> None:
 
 
 def _single_use(ctx) -> bool:
-    """Backward side: True iff every parameter of this node has exactly this one pending use (then its gradient is adopted
-    by autograd without being read).  Always takes the counters down."""
+    """Backward side: True iff every parameter of this node has exactly this one pending use and no gradient yet (then the
+    gradient returned here is adopted by autograd without being read).  Always takes the counters down."""
     ok = True
     for p in getattr(ctx, "rh_params", ()):
         n = getattr(p, "_rh_pending", 1)
         ok = ok and n == 1 and not getattr(p, "_rh_shared", False)
+        # an EXISTING gradient (accumulation over several backward() calls, zero_grad(set_to_none=False), the other
+        # optimizer's parameters in a GAN step) is accumulated into by AccumulateGrad on the COMPUTE stream -- it must not
+        # read a tensor the side stream is still writing (ADVICE r3); likewise the data-parallel hook copies a gradient
+        # into its bucket view on the compute stream when the view was not the one written (slot active but not fresh)
+        if p.grad is not None:
+            ok = False
+        slot = getattr(p, "_rh_grad_slot", None)
+        if slot is not None and len(slot) > 2 and slot[2] and not slot[1]:
+            ok = False
         p._rh_pending = max(n - 1, 0)
         if p._rh_pending == 0:
             p._rh_shared = False
@@ -472,6 +506,7 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, g, bias, alpha, residual, geom: ConvGeom, prepacked=None):
         ctx.slots = (_slot_of(weight), _slot_of(g), _slot_of(bias))
         _note_use(ctx, weight, g, bias)
+        _log_gate((weight, g, bias), x, geom.act)
         x = _chk(x, "x"); weight = _chk(weight, "weight"); g = _chk(g, "weight_g"); bias = _chk(bias, "bias")
         alpha = _chk(alpha, "alpha"); residual = _chk(residual, "residual")
         w3 = weight.reshape(weight.shape[0], weight.shape[1], -1) if weight.dim() == 4 else weight
@@ -584,6 +619,7 @@ class _ResidualUnitFn(torch.autograd.Function):
     def forward(ctx, x, w3, g3w, w1, g1w, alpha0, alpha2, g3: ConvGeom, g1: ConvGeom, pre3=None, pre1=None):
         ctx.slots = (_slot_of(w3), _slot_of(g3w), _slot_of(w1), _slot_of(g1w))
         _note_use(ctx, w3, g3w, w1, g1w)
+        gate_ids = ((w3, g3w), (w1, g1w))
         x = _chk(x, "x"); w3 = _chk(w3, "w3"); w1 = _chk(w1, "w1"); g3w = _chk(g3w, "g3"); g1w = _chk(g1w, "g1")
         alpha0 = _chk(alpha0, "alpha0"); alpha2 = _chk(alpha2, "alpha2")
         b, c, l = x.shape
@@ -602,6 +638,9 @@ class _ResidualUnitFn(torch.autograd.Function):
             h = torch.empty_like(x)
             L.check(_fwd(d3, x, wp3f, None, alpha0, None, h, s), "unit k3")
             L.check(_fwd(d1, h, wp1f, None, alpha2, x, y, s), "unit k1")
+        _log_gate(gate_ids[0], x, g3.act)
+        if h is not None:
+            _log_gate(gate_ids[1], h, g1.act)
         ctx.save_for_backward(x, h, wp3b, wp1b, alpha0, alpha2, w3 if g3w is not None else None, g3w, n3,
                               w1 if g1w is not None else None, g1w, n1)
         ctx.d3, ctx.d1 = d3, d1

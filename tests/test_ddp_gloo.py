@@ -235,6 +235,68 @@ def test_last_bucket_is_cut_short():
     assert len(GradReducer(ps[:2], bucket_mb=8.0).buckets) == 1
     assert len(GradReducer(ps, bucket_mb=32.0, tail_mb=0.0).buckets) == 2
     for p in ps:                                                             # every parameter got its view
-        v, fresh = p._rh_grad_slot
-        assert v.shape == p.shape and fresh is False
+        v, fresh, active = p._rh_grad_slot
+        assert v.shape == p.shape and fresh is False and active is False
     red.remove()
+
+
+def _worker8(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from rave_amd.ddp import BufferSync, GradReducer, broadcast_module, shard_batch
+    net = _make_net()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.1 * rank)                    # every rank starts elsewhere: the broadcast must bring rank 0's weights
+    broadcast_module(net)
+    red = GradReducer(list(net.parameters()), bucket_mb=0.0005, tail_mb=0.0002)
+    per = shard_batch(256, rank, world)           # BASELINE configs[2]: global batch 256 -> 32 clips per GPU
+    assert per == 32
+    torch.manual_seed(1)
+    x = torch.randn(256, 4, 16)
+    xs = x[rank * per:(rank + 1) * per]
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        red.begin()
+        net(xs).pow(2).mean().backward()
+        red.finish()
+        if step == 0:
+            g0 = [p.grad.clone() for p in net.parameters()]
+        opt.step()
+    torch.save((rank, g0, [p.detach().clone() for p in net.parameters()], len(red.buckets), red.bytes_reduced,
+                red.bytes_overlapped), os.path.join(outdir, f"w8_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_partition_and_buckets(tmp_path):
+    """the N = 8 partition / bucket logic executed at least once (gloo, CPU): shard_batch(256, r, 8) = 32
+    clips per rank, the bucketed all-reduce of 8 ranks equals the gradient of the full batch of 256, and two optimizer
+    steps leave every rank with identical parameters."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    out = [torch.load(os.path.join(str(tmp_path), f"w8_{r}.pt"), weights_only=False) for r in range(world)]
+    net = _make_net()
+    torch.manual_seed(1)
+    x = torch.randn(256, 4, 16)
+    net(x).pow(2).mean().backward()
+    for rank, g0, params, n_buckets, reduced, overlapped in out:
+        assert n_buckets >= 2 and reduced > 0 and overlapped > 0
+        for g, p in zip(g0, net.parameters()):
+            assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-7)
+        for a, b in zip(params, out[0][2]):
+            assert torch.equal(a, b)             # every rank holds rank 0's parameters after two steps
+    from rave_amd.ddp import shard_batch
+    import pytest
+    with pytest.raises(ValueError):
+        shard_batch(100, 0, 8)
