@@ -129,15 +129,52 @@ def cpu_baseline(n_signal: int, budget_s: float = 25.0):
             "v2_small_forward_loss": small}
 
 
+def _lib_sha():
+    import hashlib
+    from rave_amd import _lib as L
+    with open(L.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def _pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel family from the committed PMC summary (see roofline.traffic_note)."""
+    """(HBM bytes per launch of the dominant kernel family, note) from the newest committed PMC summary.  SELF-CHECKING
+    (VERDICT r3 #8): tools/final_measure.sh stamps the summary with the sha256 of the librave_hip.so the counters were
+    collected on; a different library is loaded now -> traffic null + a note (the figure would silently be stale)."""
     fam = {"conv_x6_kernel": "conv_x6(fwd+dgrad)", "wgrad_x6_kernel": "wgrad_x6", "wgrad_dma_kernel": "wgrad_f32",
            "conv_igemm_dma_kernel": "conv_f32(fwd+dgrad)"}.get(kernel_name)
+    for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            sha = d.get("librave_hip_sha256")
+            if sha is None:
+                return None, f"profiles/{name} carries no library stamp (collected before round 4): not used"
+            if sha != _lib_sha():
+                return None, (f"profiles/{name} was collected on librave_hip.so sha256 {sha[:16]}..., the loaded library is "
+                              f"{_lib_sha()[:16]}...: stale, not reported -- re-run tools/final_measure.sh (PARTS=pmc)")
+            return float(d[fam]["hbm_bytes_per_launch"]), f"profiles/{name}, library stamp verified ({sha[:16]}...)"
+        except Exception as e:                      # noqa: BLE001
+            return None, f"profiles/{name}: {e!r}"
+    return None, "no PMC summary committed"
+
+
+def x6_products_leg():
+    """SECONDARY keys forward_only_x3 / forward_only_x4: the forward leg on the 3- / 4-partial-product
+    measurement builds of the bf16 kernels (rave_amd/_var/, tools/x6_products.py; one subprocess per library).  Labelled
+    with their dtype; the headline and ``forward_only`` stay on the 6-product (f32-class) path."""
+    import subprocess
     try:
-        with open(os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")) as f:
-            return float(json.load(f)[fam]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "x6_products.py"), "--json"], capture_output=True,
+                           text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("X6_PRODUCTS ")]
+        if r.returncode != 0 or not line:
+            return {"forward_only_x_error": (r.stderr or r.stdout)[-400:]}
+        return json.loads(line[-1][len("X6_PRODUCTS "):])
+    except Exception as e:                          # noqa: BLE001 -- secondary keys never break the headline
+        return {"forward_only_x_error": repr(e)}
 
 
 def main():
@@ -159,6 +196,8 @@ def main():
                          "bucket all-reduces into the same graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-products-leg", action="store_true",
+                    help="skip the secondary forward_only_x3 / _x4 legs (3- / 4-partial-product measurement builds)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -304,9 +343,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config} config, batch {args.batch} {'stereo' if n_ch == 2 else 'mono'} 44.1 kHz "
                                f"n_signal={args.n_signal}, "
-                               f"{'VAE' if args.phase == 'vae' else 'VAE+GAN'}-phase training step per GPU"
+                               f"{'VAE' if args.phase == 'vae' else 'VAE+GAN'}-phase training step per GPU (--phase {args.phase})"
                                + (" [opt-in: dead gradients skipped]" if args.skip_dead_grads else ""),
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "phase": args.phase},
         "per_gpu_samples_per_s": samples / dt / world,
         "ms_per_step_median_hip_events": per_step[len(per_step) // 2] if per_step else None,
         "step_mode": "hipGraph replay (rave_amd.model.GraphedTrainingStep)" if use_graph else "eager",
@@ -361,12 +400,13 @@ def main():
             "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
             "frac": fl / (ms * 1e-3) / peak, "frac_vs_exact_f32_peak": fl / (ms * 1e-3) / F32_MFMA_PEAK,
             "frac_vs_sustained_mfma_rate": (fl / (ms * 1e-3) / X6_MFMA_SUSTAINED) if peak == X6_MFMA_PEAK else None,
-            "traffic": _pmc_traffic(dom_name),
+            "traffic": _pmc_traffic(dom_name)[0],
+            "traffic_source": _pmc_traffic(dom_name)[1],
             "traffic_note": "HBM bytes per launch (read + write) of this kernel family from rocprofv3 --pmc FETCH_SIZE / "
                             "WRITE_SIZE passes over this command (separate passes, tools/final_measure.sh), with read / write "
-                            "factors calibrated on tools/probe/fetch_calib in the same call; committed as "
-                            "profiles/round3_pmc_traffic.json and read from there (the counters cannot be collected inside the "
-                            "timed process); null if that file is absent",
+                            "factors calibrated on tools/probe/fetch_calib in the same call; committed under profiles/ with the "
+                            "sha256 of the library it was collected on and read from there (the counters cannot be collected "
+                            "inside the timed process); null when the loaded library differs from that stamp",
             "algorithmic_bytes_per_launch": by / n,
             "launches_per_step": n // reps, "avg_launch_ms": ms / n,
             "avg_call_ms": cms / n,
@@ -433,6 +473,9 @@ def main():
                                "f32_mfma_frac": ff / t_fwd / F32_MFMA_PEAK,
                                "x6_mfma_frac": ff / t_fwd / X6_MFMA_PEAK,
                                "samples_per_s": args.batch * args.n_signal / t_fwd}
+    if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_products_leg and args.config == "v2" \
+            and args.batch == 32 and args.n_signal == 65536:
+        out.update(x6_products_leg())
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "v2":
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
     if use_ddp:

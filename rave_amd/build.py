@@ -75,5 +75,57 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# Measurement libraries (never loaded by the product path: rave_amd._lib takes them only through RAVE_HIP_LIB): the bf16x6
+# forward / data-gradient kernels with 3 or 4 partial products instead of 6 (common.hpp: RH_X6_PRODUCTS; bench.py's
+# forward_only_x3 / _x4 legs, tools/x6_products.py).  Only the sources that see the macro are recompiled.
+VARIANT_SOURCES = ["conv_x6_is1.hip", "conv_x6_is2.hip", "conv_x6_is4.hip", "unit_x6.hip", "conv_host.hip"]
+VAR = os.path.join(HERE, "_var")
+
+
+def variant_lib(products: int) -> str:
+    return os.path.join(VAR, f"librave_hip_p{products}.so")
+
+
+def build_variants(products=(3, 4), force: bool = False) -> list:
+    build()
+    os.makedirs(VAR, exist_ok=True)
+    hip = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, libs = [], []
+    for n in products:
+        for s in VARIANT_SOURCES:
+            src = os.path.join(CSRC, s)
+            obj = os.path.join(VAR, f"{s}.p{n}.o")
+            stamp = obj + ".sha"
+            dig = _digest([src] + hdrs) + f"-p{n}"
+            if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+                continue
+            jobs.append((f"{s} [products {n}]", [hip] + FLAGS + [f"-DRH_X6_PRODUCTS={n}", "-x", "hip", "-c", src, "-o", obj], stamp, dig))
+
+    def run(job):
+        name, cmd, stamp, dig = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {name}:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(dig)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    for n in products:
+        lib = variant_lib(n)
+        objs = [os.path.join(VAR, f"{s}.p{n}.o") if s in VARIANT_SOURCES else os.path.join(OBJ, s + ".o") for s in SOURCES]
+        newest = max(os.path.getmtime(o) for o in objs)
+        if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+            r = subprocess.run([hip, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        libs.append(lib)
+    return libs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--variants" in sys.argv:
+        print(build_variants(force="--force" in sys.argv))

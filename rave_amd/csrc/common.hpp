@@ -62,5 +62,46 @@ __device__ __forceinline__ float rh_max1(float a, float b) {
     return r;
 }
 
+// Measurement builds only (tools/x6_products.sh, never the product library): RH_X6_PRODUCTS = 3 | 4 replaces the exact
+// 3-way bf16 split of the bf16x6 forward / data-gradient kernels by a 2-piece split -- a1 = the high half of the float
+// (truncation), a2 = the remainder rounded to nearest-even bf16 -- and the six partial products by a1b1 + a1b2 + a2b1
+// (3) or those + a2b2 (4), smallest terms first.  a1 + a2 represents a to 2^-17 relative, the dropped a2b2 is <= 2^-16 |ab|:
+// NOT the f32 numerics class of the 6-product kernels; SURVEY.md section 7 option (i), measured against north_star's
+// 1e-4 bar in profiles/round4_x6_products.md.  Weight gradients keep their six products.
+#ifndef RH_X6_PRODUCTS
+#define RH_X6_PRODUCTS 6
+#endif
+#if RH_X6_PRODUCTS == 6
+#define RH_X6_NPROD 6
+#define RH_X6_NPIECE 3
+#define RH_X6_SA {2, 0, 1, 1, 0, 0}
+#define RH_X6_SB {0, 2, 1, 0, 1, 0}
+#elif RH_X6_PRODUCTS == 4
+#define RH_X6_NPROD 4
+#define RH_X6_NPIECE 2
+#define RH_X6_SA {1, 1, 0, 0}
+#define RH_X6_SB {1, 0, 1, 0}
+#elif RH_X6_PRODUCTS == 3
+#define RH_X6_NPROD 3
+#define RH_X6_NPIECE 2
+#define RH_X6_SA {1, 0, 0}
+#define RH_X6_SB {0, 1, 0}
+#else
+#error "RH_X6_PRODUCTS must be 6, 4 or 3"
+#endif
+// The three bf16 pieces of v as bit patterns whose HIGH halves are the pieces (the packers take the high halves).
+__device__ __forceinline__ void rh_x6_split(float v, unsigned& h0, unsigned& h1, unsigned& h2) {
+    h0 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(h0 & 0xffff0000u);
+#if RH_X6_PRODUCTS == 6
+    h1 = __float_as_uint(r1);
+    h2 = __float_as_uint(r1 - __uint_as_float(h1 & 0xffff0000u));
+#else
+    const unsigned u = __float_as_uint(r1);
+    h1 = u + 0x7fffu + ((u >> 16) & 1u);      // round to nearest-even at bit 16
+    h2 = 0u;
+#endif
+}
+
 static inline int rh_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t rh_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

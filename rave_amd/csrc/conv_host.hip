@@ -222,11 +222,8 @@ void plan_to_x6(const TapPlan& t, int inner, ConvP* p) {
 constexpr int kPackSlots = 4;      // slots per pass: 16.9 KB of LDS (8 slots: 385 us for the v2 model's repack, 4: 314)
 
 __device__ __forceinline__ void split3_bits(float x, unsigned& a, unsigned& b, unsigned& c) {
-    a = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(a);
-    b = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(b);
-    c = __float_as_uint(r2) & 0xffff0000u;
+    rh_x6_split(x, a, b, c);          // (common.hpp: exact 3-way split; 2 pieces in the RH_X6_PRODUCTS measurement builds)
+    a &= 0xffff0000u; b &= 0xffff0000u; c &= 0xffff0000u;
 }
 
 __host__ __device__ __forceinline__ long pack_tiles(const PackP& q) {

@@ -126,10 +126,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float a = rh_max1(v[i], v[i] * slope);
-            h[0][i] = __float_as_uint(a);
-            const float r1 = a - __uint_as_float(h[0][i] & 0xffff0000u);
-            h[1][i] = __float_as_uint(r1);
-            h[2][i] = __float_as_uint(r1 - __uint_as_float(h[1][i] & 0xffff0000u));
+            rh_x6_split(a, h[0][i], h[1][i], h[2][i]);
         }
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3)
@@ -172,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
     convert_x(0);
     if (nchunks > 1) load_x(1);
     __syncthreads();
-    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+    constexpr int SA[RH_X6_NPROD] = RH_X6_SA, SB[RH_X6_NPROD] = RH_X6_SB;     // smallest terms first
     int st = 0;
     int toff_next = p.off[tap0] - minoff;
     for (int ci = 0; ci < nchunks; ++ci) {
@@ -202,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
                 if (ci + 2 < nchunks) load_x(ci + 2);
             }
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < RH_X6_NPROD; ++q)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -286,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
 #pragma unroll
                 for (int s3 = 0; s3 < 3; ++s3) afr2[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < RH_X6_NPROD; ++q)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
                     acc2[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr2[tm][SA[q]], bfr2[SB[q]], acc2[tm][0], 0, 0, 0);

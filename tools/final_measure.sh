@@ -1,7 +1,7 @@
-# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/r3/ (copied into profiles/round3_*)
+# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/r4/ (copied into profiles/round4_*)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r3; mkdir -p $O
+O=gpurun_out/r4; mkdir -p $O
 PARTS=${PARTS:-all}
 has() { [ "$PARTS" = all ] || echo " $PARTS " | grep -q " $1 "; }
 if has probes; then      # (binaries: bash tools/probe/build.sh in the build container)

@@ -76,6 +76,10 @@ def main(fetch_db, write_db, out, cal_fetch=None, cal_write=None):
                           "--steps 2 --warmup 1 --no-graph` (v2, batch 32 x 65536, VAE phase); bytes = factor * counter KB * 1024 with "
                           "the factors " + ("measured in the same call on tools/probe/fetch_calib (256 MiB per access pattern)"
                                             if calibrated else "of the guide (wide streaming reads: FETCH x 2, uncalibrated for these patterns)"))
+    # stamp: the library the counters were collected on -- bench.py reports `traffic` only while it loads the same one
+    import hashlib, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rave_amd", "librave_hip.so")
+    res["librave_hip_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "_provenance"}, indent=1))
 
