@@ -277,6 +277,10 @@ int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const float* wp_f
 /* dx = conv2d^T(dy * act'(y)); y may be null when act == RH_ACT_NONE. */
 int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* wp_bwd, float* dx,
                            rh_stream_t stream);
+/* Diagnostics (tests): kernel family and tile plan of a forward (which = 0) / data-gradient (1) launch.
+ * out[16] = {family: 0 f32-input MFMA, 1 bf16x6 (conv2d_x6.hip), 2 vector ALU (conv2d_smallm.hip: <= 4 output rows); tm; tn; conversion tasks per thread; TR; TQ; nb; LDS bytes;
+ *            workgroups; PH; PW; P (patch positions); largest tap offset in the patch; phases; row tiles; column tiles} */
+int rh_conv2d_plan_info(const rh_conv2d_desc* d, int32_t which, int64_t* out);
 int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d);
 /* dw (c_out, c_in, kh, kw), dbias (c_out) or null; deterministic (ordered split-K partials in `workspace`). */
 int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x, float* dw,

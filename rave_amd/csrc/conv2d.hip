@@ -14,6 +14,12 @@
 #include <cstdlib>
 #include <mutex>
 #include "conv_params.hpp"
+#include "conv2d_x6.hpp"
+
+// conv2d_smallm.hip: vector-ALU kernels for convolutions with <= 4 output rows (first-layer data gradient, scoring conv)
+bool rh_conv2d_smallm_eligible(const rh_conv2d_desc* d, int which);
+int rh_conv2d_smallm_launch(const rh_conv2d_desc* d, int which, const float* in, const float* wp, const float* bias, float* out,
+                            hipStream_t stream);
 
 namespace {
 
@@ -1125,7 +1131,38 @@ int fill_pack2(const rh_conv2d_desc* d, int which, const float* w, float* wp, Pa
     p->total = (long)t.nslots * p->C * p->Mp;
     p->nslots = t.nslots;
     for (int i = 0; i < t.nslots; ++i) p->kk[i] = t.kk[i];
+    // bf16x6 section behind the f32 one (conv2d_x6.hip): fragments [phase][chunk][tap][g][piece][Mp] -- the mode-1 layout
+    // of the 1-D packer with (kh, kw) taps as its taps
+    long ph_ofs[kPh2];
+    const long units = rh_conv2d_x6_units(p->C, p->M, t.nphase, t.ntaps, ph_ofs);
+    if (units > 0 && units * 4 < 0x7fffffffl) {
+        p->wq = reinterpret_cast<unsigned*>(wp + p->total);
+        p->x6_mode = 1;
+        for (int ph = 0; ph < t.nphase; ++ph)
+            for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
+                p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 6 * p->Mp);
+                p->q2n[t.tap0[ph] + tl] = t.ntaps[ph] * 6 * p->Mp;
+            }
+    }
     return RH_OK;
+}
+
+// Parameters of the bf16x6 launch (conv2d_x6.hip) from the tap plan; the tile plan is made there.
+void fill_c2x(const Plan2& t, int C, int M, const float* wp, C2X* q) {
+    *q = C2X{};
+    q->C = C; q->M = M; q->Mp = round32(M);
+    q->nphase = t.nphase;
+    const long total = (long)t.nslots * C * q->Mp;
+    const long units = rh_conv2d_x6_units(C, M, t.nphase, t.ntaps, q->ph_q2ofs);
+    q->wq = (units > 0 && units * 4 < 0x7fffffffl) ? reinterpret_cast<const unsigned*>(wp + total) : nullptr;
+    q->wq_bytes = (unsigned)(units * 16);
+    for (int ph = 0; ph < t.nphase; ++ph) {
+        q->ph_oph_h[ph] = t.oph_h[ph]; q->ph_oph_w[ph] = t.oph_w[ph];
+        q->ph_ntaps[ph] = t.ntaps[ph]; q->ph_tap0[ph] = t.tap0[ph];
+        q->ph_minh[ph] = t.minh[ph]; q->ph_minw[ph] = t.minw[ph];
+        q->ph_maxh[ph] = t.maxh[ph]; q->ph_maxw[ph] = t.maxw[ph];
+    }
+    for (int i = 0; i < t.nslots; ++i) { q->offh[i] = t.offh[i]; q->offw[i] = t.offw[i]; }
 }
 
 }  // namespace
@@ -1134,7 +1171,59 @@ extern "C" int64_t rh_conv2d_packed_floats(const rh_conv2d_desc* d, int which) {
     if (validate2(d)) return -1;
     const int64_t M = which == 0 ? d->c_out : d->c_in;
     const int64_t C = which == 0 ? d->c_in : d->c_out;
-    return (int64_t)d->kh * d->kw * C * round32((int)M);
+    const int64_t base = (int64_t)d->kh * d->kw * C * round32((int)M);
+    // + the bf16x6 fragments of the same weights (6 bytes per weight: conv2d_x6.hip), for channel counts in blocks of 16
+    const int T = d->kh * d->kw;
+    const long units = rh_conv2d_x6_units((int)C, (int)M, 1, &T, nullptr);
+    return base + ((units > 0 && units * 4 < 0x7fffffffl) ? units * 4 : 0);
+}
+
+// Diagnostics (tests): which kernel family a forward (which = 0) / data-gradient (1) launch of this geometry takes and, for
+// the bf16x6 kernels, its tile plan.  out[16] = {family (0 = f32-input MFMA, 1 = bf16x6, 2 = vector ALU: conv2d_smallm.hip), tm, tn, tasks per thread, TR, TQ,
+// nb, LDS bytes, workgroups, PH, PW, P, largest tap offset inside the patch, phases, row tiles, column tiles}.
+extern "C" int rh_conv2d_plan_info(const rh_conv2d_desc* d, int32_t which, int64_t* out) {
+    if (int e = validate2(d)) return e;
+    RH_REQUIRE(out && (which == 0 || which == 1), RH_ERR_INVALID, "conv2d_plan_info: bad arguments");
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    rh_conv2d_desc dd = *d;
+    if (which == 1) dd.act = RH_ACT_NONE;              // (the data gradient sees dy with act'(y) folded in)
+    if (rh_conv2d_smallm_eligible(&dd, which)) { out[0] = 2; return RH_OK; }
+    Plan2 t;
+    build_plan2(d, which, &t);
+    C2X q;
+    static float dummy_w[4] __attribute__((aligned(16)));
+    const int C = which == 0 ? d->c_in : d->c_out, M = which == 0 ? d->c_out : d->c_in;
+    fill_c2x(t, C, M, dummy_w, &q);
+    if (!q.wq) return RH_OK;
+    q.wq = reinterpret_cast<const unsigned*>(dummy_w);      // (alignment test only: nothing is launched)
+    q.in = dummy_w; q.out = dummy_w;
+    q.B = d->batch;
+    if (which == 0) {
+        q.in_h = d->h_in; q.in_w = d->w_in; q.out_h = d->h_out; q.out_w = d->w_out; q.rows = d->h_out; q.qcols = d->w_out;
+        q.is_h = d->sh; q.is_w = d->sw; q.os_h = 1; q.os_w = 1;
+    } else {
+        q.in_h = d->h_out; q.in_w = d->w_out; q.out_h = d->h_in; q.out_w = d->w_in;
+        q.rows = rh_cdiv(d->h_in, d->sh); q.qcols = rh_cdiv(d->w_in, d->sw);
+        q.is_h = 1; q.is_w = 1; q.os_h = d->sh; q.os_w = d->sw;
+    }
+    long v[8];
+    if (!rh_conv2d_x6_plan_query(q, v)) return RH_OK;
+    out[0] = 1;
+    for (int i = 0; i < 8; ++i) out[1 + i] = v[i];
+    // (the query works on a copy: redo the geometry-only part for the patch figures)
+    int span_h = 0, span_w = 0;
+    for (int ph = 0; ph < t.nphase; ++ph) {
+        if (t.ntaps[ph] < 1) continue;
+        span_h = span_h > t.maxh[ph] - t.minh[ph] ? span_h : t.maxh[ph] - t.minh[ph];
+        span_w = span_w > t.maxw[ph] - t.minw[ph] ? span_w : t.maxw[ph] - t.minw[ph];
+    }
+    const long TR = v[3], TQ = v[4], nb = v[5];
+    const long PH = (TR - 1) * q.is_h + span_h + 1, PW = (TQ - 1) * q.is_w + span_w + 1;
+    out[9] = PH; out[10] = PW; out[11] = nb * PH * PW;
+    out[12] = (long)span_h * PW + span_w;
+    out[13] = t.nphase;
+    out[14] = rh_cdiv(q.rows, (int)TR); out[15] = rh_cdiv(q.qcols, (int)TQ);
+    return RH_OK;
 }
 
 extern "C" int rh_conv2d_pack_f32(const rh_conv2d_desc* d, const float* w, float* wp_fwd, float* wp_bwd,
@@ -1163,6 +1252,22 @@ extern "C" int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const 
     p.is_h = d->sh; p.is_w = d->sw; p.os_h = 1; p.os_w = 1;
     p.mul_act = RH_ACT_NONE; p.mul_slope = 0.f;
     p.epi_act = d->act; p.epi_slope = d->act_slope;
+    if (rh_conv2d_smallm_eligible(d, 0)) return rh_conv2d_smallm_launch(d, 0, x, wp_fwd, bias, y, (hipStream_t)stream);
+    {   // exact f32 on the bf16 matrix cores where the geometry allows (C in blocks of 16): conv2d_x6.hip
+        C2X q;
+        fill_c2x(t, d->c_in, d->c_out, wp_fwd, &q);
+        if (q.wq) {
+            q.in = x; q.out = y; q.bias = bias;
+            q.B = d->batch;
+            q.in_h = d->h_in; q.in_w = d->w_in; q.out_h = d->h_out; q.out_w = d->w_out;
+            q.rows = d->h_out; q.qcols = d->w_out;
+            q.is_h = d->sh; q.is_w = d->sw; q.os_h = 1; q.os_w = 1;
+            q.out_act = d->act; q.out_slope = d->act_slope;
+            bool used = false;
+            if (int e = rh_conv2d_x6_launch(q, (hipStream_t)stream, "conv2d_fwd_x6", &used)) return e;
+            if (used) return RH_OK;
+        }
+    }
     return launch_conv2(p, t, (hipStream_t)stream, "conv2d_fwd");
 }
 
@@ -1184,6 +1289,22 @@ extern "C" int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, 
     p.is_h = 1; p.is_w = 1; p.os_h = d->sh; p.os_w = d->sw;
     p.mul_act = d->act; p.mul_slope = d->act_slope;
     p.epi_act = RH_ACT_NONE; p.epi_slope = 0.f;
+    if (rh_conv2d_smallm_eligible(d, 1)) return rh_conv2d_smallm_launch(d, 1, dy, wp_bwd, nullptr, dx, (hipStream_t)stream);
+    if (d->act == RH_ACT_NONE) {   // (the caller has folded act'(y) into dy: rave_amd.ops._Conv2dFn.backward)
+        C2X q;
+        fill_c2x(t, d->c_out, d->c_in, wp_bwd, &q);
+        if (q.wq) {
+            q.in = dy; q.out = dx; q.bias = nullptr;
+            q.B = d->batch;
+            q.in_h = d->h_out; q.in_w = d->w_out; q.out_h = d->h_in; q.out_w = d->w_in;
+            q.rows = rh_cdiv(d->h_in, d->sh); q.qcols = rh_cdiv(d->w_in, d->sw);
+            q.is_h = 1; q.is_w = 1; q.os_h = d->sh; q.os_w = d->sw;
+            q.out_act = RH_ACT_NONE; q.out_slope = 0.f;
+            bool used = false;
+            if (int e = rh_conv2d_x6_launch(q, (hipStream_t)stream, "conv2d_bwd_data_x6", &used)) return e;
+            if (used) return RH_OK;
+        }
+    }
     return launch_conv2(p, t, (hipStream_t)stream, "conv2d_bwd_data");
 }
 

@@ -710,6 +710,10 @@ def _conv2d_cost(d: "L.Conv2dDesc"):
 def _launch2(kind: str, d, fn):
     if _PROFILE is None:
         return fn()
+    if kind in ("conv2d_fwd", "conv2d_dgrad"):     # which kernel family does this launch take? (rh_conv2d_plan_info)
+        info = (C.c_int64 * 16)()
+        if L.lib.rh_conv2d_plan_info(C.byref(d), 0 if kind == "conv2d_fwd" else 1, info) == 0:
+            kind += _FAMILY.get(int(info[0]), "[f32]")
     f, b = _conv2d_cost(d)
     return _timed(kind, f, b, fn)
 

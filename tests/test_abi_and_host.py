@@ -409,3 +409,61 @@ def test_stft_loss_launch_plans_cover_every_geometry():
                 checked += 1
     assert checked > 150
     assert L.lib.rh_stft_loss_plan_info(2048, 1024, 4, out) < 0       # reflect padding needs t > n_fft / 2
+
+
+def test_conv2d_x6_tile_plans_cover_every_geometry():
+    """Host side of the bf16x6 general Conv2d (conv2d_x6.hip) through rh_conv2d_plan_info, forward and data gradient of the
+    real Encodec / MRD layer geometries at several plane sizes and batches plus awkward ones: the tile grid covers the
+    per-phase output grid, the patch image fits the LDS and the conversion-task slots, every tap offset stays inside the
+    patch, channel counts outside blocks of 16 stay on the f32 kernels, and the packed operand grows by the bf16x6 section."""
+    import ctypes as C
+    from rave_amd import _lib as L
+    out = (C.c_int64 * 16)()
+    layers = [((9, 3), (2, 1), (1, 1), (4, 1)), ((9, 3), (2, 1), (1, 2), (4, 2)), ((9, 3), (2, 1), (1, 4), (4, 4)),
+              ((3, 3), (1, 1), (1, 1), (1, 1)), ((3, 9), (1, 2), (1, 1), (1, 4)), ((3, 9), (1, 1), (1, 1), (1, 4)),
+              ((5, 1), (3, 1), (1, 1), (2, 0)), ((4, 3), (3, 2), (2, 2), (3, 2)), ((2, 2), (4, 1), (1, 1), (0, 0)),
+              ((1, 1), (1, 1), (1, 1), (0, 0))]
+    planes = [(2049, 61), (1025, 125), (513, 253), (129, 1021), (33, 509), (17, 1021), (129, 26), (129, 102), (7, 6), (9, 1)]
+    checked = x6 = smallm = 0
+    for (kh, kw), (sh, sw), (dh, dw), (ph, pw) in layers:
+        for h, w in planes:
+            ho = (h + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+            wo = (w + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+            if h + 2 * ph - dh * (kh - 1) - 1 < 0 or w + 2 * pw - dw * (kw - 1) - 1 < 0:
+                continue
+            for batch, ci, co in ((64, 32, 32), (2, 32, 1), (3, 48, 96), (1, 16, 40), (2, 2, 32), (2, 24, 32)):
+                d = L.Conv2dDesc(batch=batch, c_in=ci, c_out=co, h_in=h, w_in=w, h_out=ho, w_out=wo, kh=kh, kw=kw, sh=sh, sw=sw,
+                                 dh=dh, dw=dw, ph=ph, pw=pw, act=1, act_slope=0.2)
+                for which in (0, 1):
+                    assert L.lib.rh_conv2d_plan_info(C.byref(d), which, out) == 0
+                    fam, tm, tn, nq, TR, TQ, nb, lds, wgs, PH, PW, P, maxoff, nphase, tiles_r, tiles_q = list(out)
+                    cin = ci if which == 0 else co
+                    m = co if which == 0 else ci
+                    base = kh * kw * cin * ((m + 31) // 32 * 32)
+                    packed = L.lib.rh_conv2d_packed_floats(C.byref(d), which)
+                    checked += 1
+                    if fam == 2:          # <= 4 output rows, stride 1, kh in (3, 9): vector-ALU kernels (conv2d_smallm.hip)
+                        assert m <= 4 and (sh, sw) == (1, 1) and dh == 1 and kh in (3, 9)
+                        smallm += 1
+                        continue
+                    assert not (m <= 4 and (sh, sw) == (1, 1) and dh == 1 and kh in (3, 9))
+                    if cin % 16:
+                        assert fam == 0 and packed == base
+                        continue
+                    assert packed == base * 5 // 2                      # + 6 bytes per weight of bf16 fragments
+                    if fam == 0:          # tensors beyond the 2 GiB buffer descriptors, or no tile fits
+                        assert 4 * batch * max(ci * h * w, co * ho * wo) >= 2 ** 31 - 1 or P == 0
+                        continue
+                    x6 += 1
+                    rows, qcols = (ho, wo) if which == 0 else (-(-h // sh), -(-w // sw))
+                    assert tm in (1, 2, 3) and tn in (1, 2) and nq in (4, 8) and 32 * tm * (-(-m // (32 * tm))) >= m
+                    assert TR * TQ * nb == 128 * tn and TQ <= 32
+                    assert tiles_r * TR >= rows and tiles_q * TQ >= qcols and (tiles_r - 1) * TR < rows and (tiles_q - 1) * TQ < qcols
+                    assert 2 * P <= 256 * nq and P == nb * PH * PW
+                    assert lds == (2 * 6 * 32 * tm + 6 * P) * 16 and lds <= 160 * 1024
+                    is_h, is_w = (sh, sw) if which == 0 else (1, 1)
+                    # the farthest fragment a lane reads: last row / column of the tile + the largest tap offset
+                    assert (nb - 1) * PH * PW + (TR - 1) * is_h * PW + (TQ - 1) * is_w + maxoff < P
+                    assert nphase == (1 if which == 0 else sh * sw)
+                    assert wgs == -(-batch // nb) * tiles_r * tiles_q * (-(-m // (32 * tm))) * nphase
+    assert checked > 500 and x6 > 200 and smallm > 20

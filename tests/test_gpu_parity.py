@@ -729,11 +729,30 @@ CONV2D_CASES = [
     (1, 5, 4, 9, 1, (3, 1), (1, 1), (1, 1), (1, 0), 0),         # W = 1
     (2, 4, 4, 16, 300, (1, 1), (1, 1), (1, 1), (0, 0), 1),      # 1x1, wide rows
     (1, 3, 4, 11, 13, (2, 2), (4, 1), (1, 1), (0, 0), 1),       # stride > kernel: data-gradient phases without taps
+    # ---- channel counts in blocks of 16: the bf16x6 kernels (conv2d_x6.hip) at the REAL layer geometries
+    (2, 32, 32, 257, 61, (9, 3), (2, 1), (1, 1), (4, 1), 1),    # Encodec block 1 at capacity 32 (256-column tile, 8 tasks per thread)
+    (2, 32, 32, 129, 61, (9, 3), (2, 1), (1, 2), (4, 2), 1),    # block 2 (128-column tile)
+    (2, 32, 32, 65, 125, (9, 3), (2, 1), (1, 4), (4, 4), 1),    # block 3
+    (2, 32, 32, 33, 253, (3, 3), (1, 1), (1, 1), (1, 1), 1),    # block 4
+    (2, 32, 1, 33, 125, (3, 3), (1, 1), (1, 1), (1, 1), 0),     # block 5: one output channel in a 32-row tile
+    (2, 32, 32, 129, 51, (3, 9), (1, 2), (1, 1), (1, 4), 1),    # MRD, stride 2 along W
+    (1, 32, 32, 129, 26, (3, 9), (1, 1), (1, 1), (1, 4), 1),    # MRD first-band width 26 < one 32-column row
+    (5, 16, 8, 7, 6, (3, 2), (2, 2), (1, 1), (1, 1), 0),        # tiny planes: batch folding, stride in both dims
+    (2, 16, 24, 19, 23, (4, 3), (3, 2), (2, 2), (3, 2), 1),     # stride + dilation in both dims, even kernel
+    (1, 16, 4, 11, 13, (2, 2), (4, 1), (1, 1), (0, 0), 1),      # stride > kernel: data-gradient phases without taps
+    (2, 48, 40, 16, 300, (1, 1), (1, 1), (1, 1), (0, 0), 1),    # 1x1, three chunks, M = 40 -> 64 rows (TM = 2)
+    (1, 64, 96, 20, 70, (3, 3), (1, 1), (1, 1), (1, 1), 1),     # 96 rows (TM = 3), four chunks
+    (1, 16, 16, 9, 1, (3, 1), (1, 1), (1, 1), (1, 0), 0),       # W = 1
 ]
 
 
+@pytest.mark.parametrize("x6", ["1", "0"])
 @pytest.mark.parametrize("case", CONV2D_CASES)
-def test_conv2d_fwd_and_grads_vs_cpu(dev, ops, case):
+def test_conv2d_fwd_and_grads_vs_cpu(dev, ops, case, x6, monkeypatch):
+    """Every geometry on both kernel families: RH_CONV2D_X6=1 (default: bf16x6 forward / data gradient where the channel
+    count comes in blocks of 16) and =0 (the f32-input MFMA kernels)."""
+    monkeypatch.setenv("RH_CONV2D_X6", x6)
+    monkeypatch.setenv("RH_CONV2D_SMALLM", x6)       # (0: also the vector-ALU kernels for <= 4 output rows off)
     B, Ci, Co, H, W, k, s, d, p, act = case
     g = torch.Generator().manual_seed(hash(case) % 100000)
     x = torch.randn(B, Ci, H, W, generator=g)
@@ -759,6 +778,28 @@ def test_conv2d_fwd_and_grads_vs_cpu(dev, ops, case):
     xg3, wg3 = xg.detach().clone().requires_grad_(True), wg.detach().clone().requires_grad_(True)
     ops.conv2d(xg3, wg3, None, s, p, d, act=ops.ACT_LEAKY if act else ops.ACT_NONE, slope=0.1).backward(cot.to(dev))
     assert torch.equal(wg2.grad, wg3.grad) and torch.equal(xg2.grad, xg3.grad)
+
+
+def test_conv2d_x6_kernels_really_run_and_agree_with_the_f32_kernels(dev, ops, monkeypatch):
+    """The two modes of the test above are two code paths (last bits differ) that agree to 2e-6 per launch, forward and
+    data gradient, at an Encodec layer geometry of BASELINE configs[3] (capacity 32, (9,3) stride (2,1) dilation (1,2))."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 32, 257, 125, generator=g).to(dev)
+    w = (torch.randn(32, 32, 9, 3, generator=g) / math.sqrt(32 * 27)).to(dev)
+    b = (torch.randn(32, generator=g) * 0.1).to(dev)
+    cot = None
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RH_CONV2D_X6", mode)
+        xx = x.clone().requires_grad_(True)
+        y = ops.conv2d(xx, w, b, (2, 1), (4, 2), (1, 2), act=ops.ACT_LEAKY, slope=0.2)
+        if cot is None:
+            cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        y.backward(cot)
+        res[mode] = (y.detach(), xx.grad.detach())
+    for a, c in zip(res["1"], res["0"]):
+        d = rel_l2(a, c)
+        assert 0.0 < d < 2e-6, d
 
 
 def test_conv2d_no_bias_and_empty_batch(dev, ops):
