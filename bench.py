@@ -249,9 +249,9 @@ def main():
         m.encoder.enabled.fill_(1)
     ddp.broadcast_module(m)
     use_ddp = world > 1 or force_dist
-    # (the discrete config initialises its RVQ codebooks with k-means inside its first training steps: host-driven,
-    # data-dependent work that a recorded graph cannot contain -- it runs the eager step)
-    use_graph = not args.no_graph and args.config != "discrete"
+    # (the discrete config initialises its RVQ codebooks with k-means inside its first training step: host-driven,
+    # data-dependent work that a recorded graph cannot contain -- those steps run eagerly BEFORE the capture, below)
+    use_graph = not args.no_graph
     gen_opt, dis_opt = m.configure_optimizers(capturable=use_graph)
     m.warmed_up = args.phase == "gan"
     m.skip_dead_grads = bool(args.skip_dead_grads)
@@ -290,15 +290,26 @@ def main():
     sync_kw = dict(grad_begin=grad_begin, grad_sync=grad_sync) if use_ddp else {}
     graphed = None
     graph_note = None
+    if use_graph and args.config == "discrete":
+        # eager steps until every codebook is initialised (one of each step kind): GraphedTrainingStep refuses an
+        # un-initialised RVQ (rave_amd/model.py: _check_capturable)
+        for i in range(2 if m.warmed_up else 1):
+            if use_ddp:
+                bufsync.sync()
+            m.training_step(x.detach().clone(), i, capture_safe=True, **sync_kw)
+            m.on_train_batch_end(None, None, i)
+        torch.cuda.synchronize()
     if use_graph:
         try:
             graphed = M.GraphedTrainingStep(m, x, before_step=(bufsync.sync if use_ddp else None), **sync_kw)
             graphed(x, 0)                 # capture now: a failure falls back to the eager step (reported)
             torch.cuda.synchronize()
         except Exception as e:            # noqa: BLE001 -- e.g. a collective the backend cannot record
-            if not use_ddp:
+            if not use_ddp and args.config == "v2":
                 raise
-            graph_note = f"hipGraph capture of the data-parallel step failed ({type(e).__name__}: {e}); eager step"
+            import traceback
+            where = [ln.strip() for ln in traceback.format_exc().splitlines() if "rave_amd" in ln][-3:]
+            graph_note = f"hipGraph capture of the step failed ({type(e).__name__}: {str(e)[:200]}); eager step; at {where}"
             graphed, use_graph = None, False
             m.configure_optimizers(capturable=False)
 

@@ -453,6 +453,16 @@ class VariationalEncoder(nn.Module):
         return z
 
 
+def _noise_like_reference(z: torch.Tensor, channels: int) -> torch.Tensor:
+    """The noise-augmentation draw of rave/blocks.py:783-786 / :820-823: ``torch.randn(...).type_as(z)``, i.e. the CPU
+    generator + a host-to-device copy, kept as is for eager steps (same random stream as the reference).  While a hipGraph is
+    being recorded a pageable host-to-device copy is not capturable: the draw then comes from the device generator (torch
+    advances its Philox offset per replay)."""
+    if z.is_cuda and torch.cuda.is_current_stream_capturing():
+        return torch.randn(z.shape[0], channels, z.shape[-1], device=z.device, dtype=z.dtype)
+    return torch.randn(z.shape[0], channels, z.shape[-1]).type_as(z)
+
+
 class WasserteinEncoder(nn.Module):
     """rave/blocks.py:748-791 (configs/wasserstein.gin): MMD regulariser on the latent -- elementwise /
     small-matrix torch ops around the HIP encoder; ``eps`` arguments inject the random draws."""
@@ -476,7 +486,7 @@ class WasserteinEncoder(nn.Module):
         reg = self.compute_mmd(z_reshaped, torch.randn_like(z_reshaped) if eps is None else eps)
         if self.noise_augmentation:
             if noise is None:
-                noise = torch.randn(z.shape[0], self.noise_augmentation, z.shape[-1]).type_as(z)
+                noise = _noise_like_reference(z, self.noise_augmentation)
             z = torch.cat([z, noise], 1)
         return z, reg.mean()
 
@@ -538,7 +548,7 @@ class DiscreteEncoder(nn.Module):
             diff = torch.zeros_like(z).mean()
         if self.noise_augmentation:
             if noise is None:
-                noise = torch.randn(z.shape[0], self.noise_augmentation, z.shape[-1]).type_as(z)
+                noise = _noise_like_reference(z, self.noise_augmentation)
             z = torch.cat([z, noise], 1)
         return z, diff
 

@@ -759,13 +759,17 @@ def test_conv2d_fwd_and_grads_vs_cpu(dev, ops, case, x6, monkeypatch):
     w = torch.randn(Co, Ci, *k, generator=g) / math.sqrt(Ci * k[0] * k[1])
     b = torch.randn(Co, generator=g) * 0.1
     xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
-    ref = F.conv2d(xd, wd, bd, s, p, d)
-    if act:
-        ref = F.leaky_relu(ref, 0.1)
-    cot = torch.randn(ref.shape, generator=g)
-    ref.backward(cot.double())
     xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
     y = ops.conv2d(xg, wg, bg, s, p, d, act=ops.ACT_LEAKY if act else ops.ACT_NONE, slope=0.1)
+    ref = F.conv2d(xd, wd, bd, s, p, d)
+    if act:
+        # the LeakyReLU gates of the reference are taken from the HIP output: an output within rounding (1e-7) of zero takes
+        # the other slope in the f64 evaluation and changes that element's gradient 10x -- one such element moves dx by 1e-3
+        # (seen on one geometry / kernel combination of this list).  The VALUES still compare: the two branches differ by
+        # 0.9 |pre-activation| ~ 1e-7 there.
+        ref = torch.where(y.detach().cpu() > 0, ref, 0.1 * ref)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot.double())
     assert y.shape == ref.shape
     assert rel_l2(y, ref) < TOL_OP
     y.backward(cot.to(dev))
