@@ -281,6 +281,8 @@ int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, const float
  * out[16] = {family: 0 f32-input MFMA, 1 bf16x6 (conv2d_x6.hip), 2 vector ALU (conv2d_smallm.hip: <= 4 output rows); tm; tn; conversion tasks per thread; TR; TQ; nb; LDS bytes;
  *            workgroups; PH; PW; P (patch positions); largest tap offset in the patch; phases; row tiles; column tiles} */
 int rh_conv2d_plan_info(const rh_conv2d_desc* d, int32_t which, int64_t* out);
+/* 1 = rh_conv2d_bwd_weight_f32 runs this geometry (act == NONE) on the bf16 matrix cores (wgrad2d_x6.hip), else 0. */
+int rh_conv2d_bwd_weight_kernel_family(const rh_conv2d_desc* d);
 int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d);
 /* dw (c_out, c_in, kh, kw), dbias (c_out) or null; deterministic (ordered split-K partials in `workspace`). */
 int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x, float* dw,

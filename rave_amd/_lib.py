@@ -84,6 +84,7 @@ def _load() -> C.CDLL:
         "rh_conv2d_bwd_data_f32": ([D2, P, P, P, P, P], C.c_int),
         "rh_conv2d_workspace_bytes": ([D2], I64),
         "rh_conv2d_plan_info": ([D2, I32, C.POINTER(I64)], C.c_int),
+        "rh_conv2d_bwd_weight_kernel_family": ([D2], C.c_int),
         "rh_conv2d_bwd_weight_f32": ([D2, P, P, P, P, P, P, I64, P], C.c_int),
         "rh_feed_batch_i16_f32": ([P, P, P, P, I32, I32, I32, P, P], C.c_int),
         "rh_vq_loss_partials": ([I64], I64),

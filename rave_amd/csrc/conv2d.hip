@@ -16,6 +16,10 @@
 #include "conv_params.hpp"
 #include "conv2d_x6.hpp"
 
+// wgrad2d_x6.hip: weight gradient on the bf16 matrix cores (<= 32 output channels, stride 1 along W)
+int64_t rh_wgrad2d_x6_workspace(const rh_conv2d_desc* d);
+int rh_wgrad2d_x6_launch(const rh_conv2d_desc* d, const float* dy, const float* x, float* dw, void* ws, int64_t ws_bytes,
+                         hipStream_t stream, bool* used);
 // conv2d_smallm.hip: vector-ALU kernels for convolutions with <= 4 output rows (first-layer data gradient, scoring conv)
 bool rh_conv2d_smallm_eligible(const rh_conv2d_desc* d, int which);
 int rh_conv2d_smallm_launch(const rh_conv2d_desc* d, int which, const float* in, const float* wp, const float* bias, float* out,
@@ -1308,6 +1312,12 @@ extern "C" int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, 
     return launch_conv2(p, t, (hipStream_t)stream, "conv2d_bwd_data");
 }
 
+// 1 = the weight gradient of this geometry runs on the bf16 matrix cores (wgrad2d_x6.hip), 0 = f32-input MFMA kernels
+extern "C" int rh_conv2d_bwd_weight_kernel_family(const rh_conv2d_desc* d) {
+    if (validate2(d) || d->act != RH_ACT_NONE) return 0;
+    return rh_wgrad2d_x6_workspace(d) >= 0 ? 1 : 0;
+}
+
 extern "C" int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d) {
     if (validate2(d)) return -1;
     if (d->batch == 0) return 0;
@@ -1321,7 +1331,10 @@ extern "C" int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d) {
     if (plan_w2_dma(q, &w, &tn)) need = w.Z > 1 ? (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
     const W2Plan g = plan_w2(p);
     const int64_t need_g = g.Z > 1 ? (int64_t)g.Z * p.M * p.C * p.T * (int64_t)sizeof(float) : 0;
-    return (need > need_g ? need : need_g) + rh_bias_grad_workspace(d->c_out);
+    int64_t best = need > need_g ? need : need_g;
+    const int64_t need_x6 = rh_wgrad2d_x6_workspace(d);
+    if (need_x6 > best) best = need_x6;
+    return best + rh_bias_grad_workspace(d->c_out);
 }
 
 extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x,
@@ -1351,6 +1364,11 @@ extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy
     }
     workspace = workspace ? (void*)((char*)workspace + bias_ws) : nullptr;
     workspace_bytes = workspace_bytes > bias_ws ? workspace_bytes - bias_ws : 0;
+    if (d->act == RH_ACT_NONE) {      // (the caller has folded act'(y) into dy) -- bf16x6 kernel where the geometry allows
+        bool used = false;
+        if (int e = rh_wgrad2d_x6_launch(d, dy, x, dw, workspace, workspace_bytes, stream, &used)) return e;
+        if (used) return RH_OK;
+    }
     Wgrad2P p;
     fill_w2(d, &p);
     p.R = dy; p.Rmul = ymul; p.S = x;

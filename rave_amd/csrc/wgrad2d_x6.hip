@@ -1,0 +1,312 @@
+// Weight gradient of the general Conv2d as exact f32 on the bf16 matrix cores (the "x6" numerics of conv_x6_kernel.inc:
+// every f32 split exactly into three bf16 pieces, six partial products per block), for the 32 -> 32-channel, 27-tap
+// layers of the spectral discriminators (rave/discriminator.py:23-74, rave/descript_discriminator.py:118-184), whose
+// weight gradients ran at 25-43 TFLOP/s on the f32-input MFMA (conv2d.hip wgrad2d_dma_kernel) and were 35 of the 77 ms of
+// an Encodec pass once forward and data gradient had moved to conv2d_x6.hip.
+//
+//   dW[m][c][th][tw] = sum_{b, r, q} G[b][m][r][q] * X[b][c][r*sh + th*dh - ph][q + tw*dw - pw]        (stride 1 along W)
+//
+// GEMM view: rows = m (<= 32), columns = (tap, channel), K = output positions.  Both operands are activations, so both
+// are converted in the kernel -- ONCE per position: a workgroup (8 waves, one per CU: 143 KB of LDS) stages, per tile of
+// TR x 32 output positions of one batch item,
+//   * G: 32 rows x TR x 32 positions and
+//   * X: 32 channels x the (TR-1)*sh + span_h + 1 by 32 + span_w patch the tile's taps touch,
+// as bf16 ELEMENT planes [piece][row or channel][position] (position-contiguous, 2 bytes per element and piece).  A K block
+// is 16 consecutive output positions of one output row; the A fragment of a lane is 8 consecutive bf16 of a G row
+// (16-byte aligned), the B fragment of column (tap, c) the 8 consecutive bf16 of channel c's patch row r*sh + th*dh
+// starting at the element offset of the tap: a 16-byte LDS read at an arbitrary 2-byte alignment, which gfx950's
+// ds_read_b128 serves correctly at 1.4x the aligned cost (tools/probe/lds_unaligned.hip) -- so a tap is an address
+// offset and NOTHING is converted per tap (the 1-D wgrad_x6_kernel converts the input once per tap: 10 VALU instructions
+// per MFMA at M = 32; here ~1.5).
+//   * column tile = one tap x 32 channels (lane j <-> channel): 27 tiles over 8 waves (4 or 3 each, 64 accumulator
+//     registers); every wave walks all K blocks of the tile with its own taps.
+//   * the next tile's samples are loaded (8 dwords per task, zero outside the plane) before the current tile's MFMAs and
+//     converted after them; two barriers per tile.
+//   * K is split over persistent workgroups (one per CU) into ordered partial tiles + rh_reduce_partials_launch:
+//     deterministic.
+#include <cstdlib>
+#include <mutex>
+#include "conv_params.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kW2Waves = 8, kW2Threads = 512;
+constexpr int kW2TQ = 32;          // output columns per tile = two K blocks
+constexpr int kW2MaxTaps = 32;     // 4 column tiles per wave x 8 waves
+
+struct W2X {
+    const float* G;                // dy * act'(y)  [B][M][r_h][r_w]
+    const float* X;                // x             [B][C][s_h][s_w]
+    float* out;                    // partials [Z][M][C*T]
+    int B, M, C, T;
+    int r_h, r_w, s_h, s_w;
+    int sh;                        // stride along H (1 along W)
+    int TR, tr_shift;              // output rows per tile (power of two)
+    int tiles_r, tiles_q, tiles_total;
+    int PH, PWp;                   // staged patch rows, row pitch in elements (multiple of 8)
+    int gp, xp;                    // element pitch of one G row image / one X channel image (16-byte slots: odd count)
+    int minh, minw;
+    int ngt, nxt;                  // conversion tasks of one tile: G, X
+    unsigned g_bytes, x_bytes;
+    int toff[kW2MaxTaps];          // element offset of a tap inside a channel's patch image
+};
+
+__device__ __forceinline__ u32x4 lds_read_b128_any(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+template <int NQX>
+__global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short* const g_img = reinterpret_cast<unsigned short*>(smem_raw);               // [3][32][gp]
+    unsigned short* const x_img = g_img + 3 * 32 * p.gp;                                      // [3][32][xp]
+    const unsigned g_base = (unsigned)(size_t)g_img, x_base = (unsigned)(size_t)x_img;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int c0 = blockIdx.y * 32;
+    const int TR = p.TR, PWp = p.PWp;
+    const int gplane = p.r_h * p.r_w, xplane = p.s_h * p.s_w;
+
+    const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // ---- conversion tasks (tile-invariant part).  G: (row m, tile row, 8-column fragment) -- one per thread at TR = 4;
+    // X: (channel, patch row, 8-column fragment), NQX per thread
+    const int gfr = kW2TQ / 8;                       // fragments per G tile row
+    const int xfr = PWp >> 3;                        // fragments per patch row
+    int gt_m, gt_r, gt_f;
+    {
+        const int e = tid;
+        gt_f = e % gfr;
+        const int rr = e / gfr;
+        gt_r = rr & (TR - 1);
+        gt_m = rr >> p.tr_shift;
+    }
+    const bool gt_task = tid < p.ngt;
+    int xt_c[NQX], xt_r[NQX], xt_f[NQX];
+#pragma unroll
+    for (int q = 0; q < NQX; ++q) {
+        const int e = tid + kW2Threads * q;
+        xt_f[q] = e % xfr;
+        const int rr = e / xfr;
+        xt_r[q] = rr % p.PH;
+        xt_c[q] = e < p.nxt ? rr / p.PH : -1;
+    }
+    float gr[8], xr[NQX][8];
+    auto load_tile = [&](int tile) {
+        const int tq = tile % p.tiles_q;
+        const int rest = tile / p.tiles_q;
+        const int tr = rest % p.tiles_r;
+        const int b = rest / p.tiles_r;
+        const int r0 = tr * TR, q0 = tq * kW2TQ;
+        {   // G fragment: row r0 + gt_r, columns q0 + 8 f .. + 7, zero beyond the output plane
+            const int r = r0 + gt_r, q = q0 + 8 * gt_f;
+            const bool ok = gt_task && gt_m < p.M && r < p.r_h;
+            const unsigned base = (unsigned)(((b * p.M + gt_m) * gplane + r * p.r_w + q) * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                gr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (ok && q + i < p.r_w) ? base + 4u * i : kOOB, 0, 0));
+        }
+        const int h0 = r0 * p.sh + p.minh, w0 = q0 + p.minw;
+#pragma unroll
+        for (int q = 0; q < NQX; ++q) {
+            const int h = h0 + xt_r[q], w = w0 + 8 * xt_f[q];
+            const bool ok = xt_c[q] >= 0 && c0 + xt_c[q] < p.C && h >= 0 && h < p.s_h;
+            const unsigned base = (unsigned)(((b * p.C + c0 + xt_c[q]) * xplane + h * p.s_w + w) * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xr[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    x_rsrc, (ok && w + i >= 0 && w + i < p.s_w) ? base + 4u * i : kOOB, 0, 0));
+        }
+    };
+    auto split_store = [&](const float (&v)[8], unsigned short* dst, int piece_stride) {
+        unsigned h[3][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            h[0][i] = __float_as_uint(v[i]);
+            const float r1 = v[i] - __uint_as_float(h[0][i] & 0xffff0000u);
+            h[1][i] = __float_as_uint(r1);
+            h[2][i] = __float_as_uint(r1 - __uint_as_float(h[1][i] & 0xffff0000u));
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            u32x4 pk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk[k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);
+            *reinterpret_cast<u32x4*>(dst + s3 * piece_stride) = pk;
+        }
+    };
+    auto convert_tile = [&]() {
+        if (gt_task) split_store(gr, g_img + gt_m * p.gp + gt_r * kW2TQ + 8 * gt_f, 32 * p.gp);
+#pragma unroll
+        for (int q = 0; q < NQX; ++q)
+            if (xt_c[q] >= 0) split_store(xr[q], x_img + xt_c[q] * p.xp + xt_r[q] * PWp + 8 * xt_f[q], 32 * p.xp);
+    };
+
+    // this wave's column tiles: taps wave, wave + 8, ...
+    unsigned boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave + kW2Waves * i;
+        boff[i] = t < p.T ? (unsigned)(2 * p.toff[t]) : 0u;
+    }
+    const unsigned a_lane = g_base + 2u * (unsigned)(j * p.gp + 8 * g);
+    const unsigned b_lane = x_base + 2u * (unsigned)(j * p.xp + 8 * g);
+    const unsigned a_piece = 2u * 32u * (unsigned)p.gp, b_piece = 2u * 32u * (unsigned)p.xp;
+
+    const int z = blockIdx.x, nz = gridDim.x;
+    int tile = z;
+    if (tile < p.tiles_total) load_tile(tile);
+    for (; tile < p.tiles_total; tile += nz) {
+        __syncthreads();                       // every wave is done reading the previous tile's images
+        convert_tile();
+        if (tile + nz < p.tiles_total) load_tile(tile + nz);
+        __syncthreads();
+        if (wave < p.T)                     // (a wave without a column tile must not leave LDS reads in flight)
+        for (int kb = 0; kb < 2 * TR; ++kb) {
+            const int r = kb >> 1, half = kb & 1;
+            const unsigned ao = a_lane + 2u * (unsigned)(r * kW2TQ + half * 16);
+            u32x4 a0 = lds_read_b128_any(ao), a1 = lds_read_b128_any(ao + a_piece), a2 = lds_read_b128_any(ao + 2 * a_piece);
+            const unsigned bo = b_lane + 2u * (unsigned)(r * p.sh * PWp + half * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (wave + kW2Waves * i >= p.T) break;                 // wave-uniform
+                u32x4 b0 = lds_read_b128_any(bo + boff[i]), b1 = lds_read_b128_any(bo + boff[i] + b_piece),
+                      b2 = lds_read_b128_any(bo + boff[i] + 2 * b_piece);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
+                const bf16x8 af[3] = {__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, a2)};
+                const bf16x8 bf[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
+                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA[q]], bf[SB[q]], acc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial tile of this slice: out[z][m][(c0 + j) * T + t]
+    const long CT = (long)p.C * p.T;
+    float* const part = p.out + (long)z * p.M * CT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave + kW2Waves * i;
+        if (t >= p.T || c0 + j >= p.C) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 4 * g + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) part[m * CT + (long)(c0 + j) * p.T + t] = acc[i][r];
+        }
+    }
+}
+
+bool w2x_enabled() {
+    for (const char* k : {"RH_WGRAD2D_X6", "RH_CONV2D_X6", "RH_CONV_X6", "RH_WGRAD_X6"}) {     // read per call (tests)
+        const char* e = getenv(k);
+        if (e && atoi(e) == 0) return false;
+    }
+    return true;
+}
+
+struct W2XPlan {
+    size_t lds;
+    int Z, nqx, groups;
+};
+
+bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
+    if (!w2x_enabled() || d->batch <= 0) return false;
+    const int T = d->kh * d->kw;
+    if (d->c_out > 32 || (d->c_in & 15) || d->sw != 1 || T > kW2MaxTaps) return false;
+    const unsigned long long g_b = 4ull * d->batch * d->c_out * (unsigned long long)d->h_out * d->w_out;
+    const unsigned long long x_b = 4ull * d->batch * d->c_in * (unsigned long long)d->h_in * d->w_in;
+    if (!(g_b < 0x7fffffffull && x_b < 0x7fffffffull)) return false;
+    *p = W2X{};
+    p->B = d->batch; p->M = d->c_out; p->C = d->c_in; p->T = T;
+    p->r_h = d->h_out; p->r_w = d->w_out; p->s_h = d->h_in; p->s_w = d->w_in;
+    p->sh = d->sh;
+    const int minh = -d->ph, minw = -d->pw;
+    const int span_h = (d->kh - 1) * d->dh, span_w = (d->kw - 1) * d->dw;
+    p->minh = minh; p->minw = minw;
+    int TR = 4;
+    while (TR > 1 && TR / 2 >= d->h_out) TR >>= 1;
+    for (;; TR >>= 1) {
+        p->TR = TR;
+        p->tr_shift = __builtin_ctz(TR);
+        p->PH = (TR - 1) * d->sh + span_h + 1;
+        p->PWp = (kW2TQ + span_w + 7) & ~7;
+        p->gp = (TR * kW2TQ) | 8;                       // 16-byte slots per row image: odd -> lanes (rows) spread over the banks
+        p->xp = p->PH * p->PWp;
+        if (((p->xp >> 3) & 1) == 0) p->xp += 8;
+        pl->lds = (size_t)3 * 32 * ((size_t)p->gp + p->xp) * 2;
+        p->ngt = 32 * TR * (kW2TQ / 8);
+        p->nxt = 32 * p->PH * (p->PWp >> 3);
+        if (pl->lds <= 160 * 1024 && p->ngt <= kW2Threads && p->nxt <= kW2Threads * 6) break;
+        if (TR == 1) return false;
+    }
+    pl->nqx = p->nxt <= kW2Threads * 3 ? 3 : 6;
+    for (int th = 0; th < d->kh; ++th)
+        for (int tw = 0; tw < d->kw; ++tw) p->toff[th * d->kw + tw] = th * d->dh * p->PWp + tw * d->dw;
+    p->tiles_r = rh_cdiv(d->h_out, TR);
+    p->tiles_q = rh_cdiv(d->w_out, kW2TQ);
+    const long tiles = (long)d->batch * p->tiles_r * p->tiles_q;
+    if (tiles >= 0x7fffffffl) return false;
+    p->tiles_total = (int)tiles;
+    pl->groups = rh_cdiv(d->c_in, 32);
+    static const int z_env = [] { const char* e = getenv("RH_WGRAD2D_X6_SLICES"); return e ? atoi(e) : 0; }();
+    int Z = z_env > 0 ? z_env : 256 / pl->groups;       // one workgroup per CU (143 KB of LDS)
+    if (Z < 1) Z = 1;
+    if (Z > tiles) Z = (int)tiles;
+    pl->Z = Z;
+    p->g_bytes = (unsigned)g_b; p->x_bytes = (unsigned)x_b;
+    return true;
+}
+
+}  // namespace
+
+// bytes of partial-tile scratch the bf16x6 weight gradient wants; -1 = geometry not eligible
+int64_t rh_wgrad2d_x6_workspace(const rh_conv2d_desc* d) {
+    W2X p;
+    W2XPlan pl{};
+    if (!plan_w2x(d, &p, &pl)) return -1;
+    return (int64_t)pl.Z * d->c_out * d->c_in * d->kh * d->kw * (int64_t)sizeof(float);
+}
+
+// dw = sum over positions of dy (x) x-patches; dy already carries act'(y).  *used = false when the geometry (or the scratch
+// offered) does not fit.
+int rh_wgrad2d_x6_launch(const rh_conv2d_desc* d, const float* dy, const float* x, float* dw, void* ws, int64_t ws_bytes,
+                         hipStream_t stream, bool* used) {
+    *used = false;
+    W2X p;
+    W2XPlan pl{};
+    if (!plan_w2x(d, &p, &pl)) return RH_OK;
+    const long nw = (long)d->c_out * d->c_in * d->kh * d->kw;
+    const int64_t need = (int64_t)pl.Z * nw * (int64_t)sizeof(float);
+    if (((uintptr_t)dy & 3) || ((uintptr_t)x & 3)) return RH_OK;
+    if (pl.Z > 1 && (!ws || ws_bytes < need)) return RH_OK;
+    p.G = dy; p.X = x;
+    p.out = pl.Z > 1 ? (float*)ws : dw;
+    auto go = [&](auto kern) {
+        static std::once_flag once;
+        std::call_once(once, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        rh_launch_main(kern, dim3((unsigned)pl.Z, (unsigned)pl.groups), dim3(kW2Threads), pl.lds, stream, p);
+    };
+    if (pl.nqx == 3) go(wgrad2d_x6_kernel<3>);
+    else go(wgrad2d_x6_kernel<6>);
+    if (int e = rh_check_launch("wgrad2d_x6")) return e;
+    *used = true;
+    if (pl.Z > 1) return rh_reduce_partials_launch((const float*)ws, dw, nw, pl.Z, stream, "wgrad2d_x6_reduce");
+    return RH_OK;
+}

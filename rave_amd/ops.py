@@ -714,6 +714,8 @@ def _launch2(kind: str, d, fn):
         info = (C.c_int64 * 16)()
         if L.lib.rh_conv2d_plan_info(C.byref(d), 0 if kind == "conv2d_fwd" else 1, info) == 0:
             kind += _FAMILY.get(int(info[0]), "[f32]")
+    elif kind == "conv2d_wgrad":
+        kind += _FAMILY.get(L.lib.rh_conv2d_bwd_weight_kernel_family(C.byref(d)), "[f32]")
     f, b = _conv2d_cost(d)
     return _timed(kind, f, b, fn)
 
