@@ -5,8 +5,9 @@
 // A 32-row MFMA tile is 3 - 12 % used there (round 3: 4 TFLOP/s, 3.5 ms per data gradient -- 17.7 of the 108 ms Encodec
 // pass).  This is vector-ALU code shaped like conv_smallc.hip: lanes run along W (every global access is a full line per
 // wave), a thread owns a strip of 8 output rows x M channels in registers, the input patch of a channel chunk sits in LDS,
-// and the weights -- identical for every lane -- arrive as scalar loads.  Per (channel, tap column) a thread reads its
-// 8 + KH - 1 strip values once and spends KH x 8 x M FMAs on them (9 FMAs per LDS read at KH = 9, M = 2).
+// and the weights of the chunk -- identical for every lane -- next to it (read as LDS broadcasts: as scalar loads from the
+// packed operand, one 128-byte line per (tap, channel), they missed the scalar cache on every tap).  Per (channel, tap
+// column) a thread reads its 8 + KH - 1 strip values once and spends KH x 8 x M FMAs on them.
 // FLOPs: 2 B M C kh kw H W, priced against the f32 vector peak (157.3 TFLOP/s with packed FMA, 78.6 plain).
 #include <cstdlib>
 #include "conv_params.hpp"
@@ -36,7 +37,8 @@ constexpr int kSmR = 8, kSmTH = 32, kSmTW = 64;
 template <int KH, int MM, int FLIP>
 __global__ __launch_bounds__(256) void conv2d_smallm_kernel(const SmallM2P p) {
     constexpr int PHt = kSmTH + KH - 1;
-    extern __shared__ float patch[];                    // [ck][PHt][PW]
+    extern __shared__ float patch[];                    // [ck][PHt][PW], then the chunk's weights [ck][kw][KH][MM]
+    float* const wsm = patch + p.ck * PHt * p.PW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx = blockIdx.x;
@@ -67,6 +69,16 @@ __global__ __launch_bounds__(256) void conv2d_smallm_kernel(const SmallM2P p) {
                 patch[row * PW + pc] = (rok && gw >= 0 && gw < p.in_w) ? src[gw] : 0.f;
             }
         }
+        // ---- and its weights, compact: the scalar loads this replaces (one 128-byte line per (tap, channel)) missed the
+        // scalar cache on every tap -- 14 TFLOP/s; as LDS broadcasts the same values cost one read per 16 FMAs
+        for (int e = tid; e < nc * p.kw * KH * MM; e += 256) {
+            const int m = e % MM;
+            int r = e / MM;
+            const int th = r % KH;
+            r /= KH;
+            const int tw = r % p.kw, c = r / p.kw;
+            wsm[e] = wp[((long)(th * p.kw + tw) * p.C + c0 + c) * p.Mp + m];
+        }
         __syncthreads();
         for (int c = 0; c < nc; ++c) {
             for (int tw = 0; tw < p.kw; ++tw) {
@@ -75,12 +87,12 @@ __global__ __launch_bounds__(256) void conv2d_smallm_kernel(const SmallM2P p) {
                 float s[kSmR + KH - 1];
 #pragma unroll
                 for (int k = 0; k < kSmR + KH - 1; ++k) s[k] = col[k * PW];
+                const float* wl = wsm + (c * p.kw + tw) * KH * MM;          // wave-uniform address: LDS broadcast
 #pragma unroll
                 for (int th = 0; th < KH; ++th) {
-                    const float* wv = wp + ((long)(th * p.kw + tw) * p.C + c0 + c) * p.Mp;     // wave-uniform: scalar loads
 #pragma unroll
                     for (int m = 0; m < MM; ++m) {
-                        const float wm = wv[m];
+                        const float wm = wl[th * MM + m];
 #pragma unroll
                         for (int i = 0; i < kSmR; ++i) acc[i][m] = fmaf(wm, s[i + (FLIP ? KH - 1 - th : th)], acc[i][m]);
                     }
@@ -156,9 +168,9 @@ int rh_conv2d_smallm_launch(const rh_conv2d_desc* d, int which, const float* in,
     const int PHt = kSmTH + d->kh - 1;
     p.ck = 4;
     while (p.ck > 1 && (size_t)p.ck * PHt * p.PW * 4 > 48 * 1024) p.ck >>= 1;
-    const size_t lds = (size_t)p.ck * PHt * p.PW * 4;
-    const dim3 grid((unsigned)((long)p.B * p.tiles_h * p.tiles_w));
     const int mm = p.M == 1 ? 1 : (p.M == 2 ? 2 : 4);
+    const size_t lds = (size_t)p.ck * (PHt * p.PW + d->kw * d->kh * mm) * 4;
+    const dim3 grid((unsigned)((long)p.B * p.tiles_h * p.tiles_w));
     if (d->kh == 9) { if (which) smallm_go<9, 1>(p, mm, grid, lds, stream); else smallm_go<9, 0>(p, mm, grid, lds, stream); }
     else            { if (which) smallm_go<3, 1>(p, mm, grid, lds, stream); else smallm_go<3, 0>(p, mm, grid, lds, stream); }
     return rh_check_launch(which ? "conv2d_smallm_dgrad" : "conv2d_smallm_fwd");

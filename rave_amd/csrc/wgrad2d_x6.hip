@@ -18,8 +18,13 @@
 // ds_read_b128 serves correctly at 1.4x the aligned cost (tools/probe/lds_unaligned.hip) -- so a tap is an address
 // offset and NOTHING is converted per tap (the 1-D wgrad_x6_kernel converts the input once per tap: 10 VALU instructions
 // per MFMA at M = 32; here ~1.5).
-//   * column tile = one tap x 32 channels (lane j <-> channel): 27 tiles over 8 waves (4 or 3 each, 64 accumulator
-//     registers); every wave walks all K blocks of the tile with its own taps.
+//   * GEMM column n = tap * Cg + channel (Cg = the workgroup's channels, <= 32): at C = 32 a column tile is one tap x 32
+//     channels -- 27 tiles over 8 waves (4 or 3 each, 64 accumulator registers); at C = 2 (the first layer: 54 columns)
+//     two tiles of 16 taps x 2 channels, every lane with its own (tap, channel) offset.  Every wave walks all K blocks of
+//     the tile with its own column tiles.
+//   * stride 2 along W (descript MRD, (3,9) kernels): the patch is staged as two PARITY planes (even / odd input columns),
+//     so that the 8 K positions of a fragment are again 8 consecutive elements; a conversion task takes 16 consecutive
+//     input columns and writes one fragment into each plane.
 //   * the next tile's samples are loaded (8 dwords per task, zero outside the plane) before the current tile's MFMAs and
 //     converted after them; two barriers per tile.
 //   * K is split over persistent workgroups (one per CU) into ordered partial tiles + rh_reduce_partials_launch:
@@ -46,7 +51,8 @@ struct W2X {
     int sh;                        // stride along H (1 along W)
     int TR, tr_shift;              // output rows per tile (power of two)
     int tiles_r, tiles_q, tiles_total;
-    int PH, PWp;                   // staged patch rows, row pitch in elements (multiple of 8)
+    int PH, PWp;                   // staged patch rows, row pitch in elements (multiple of 8; per parity plane at stride 2)
+    int sw;                        // stride along W: 1, or 2 (two parity planes per channel image)
     int gp, xp;                    // element pitch of one G row image / one X channel image (16-byte slots: odd count)
     int minh, minw;
     int ngt, nxt;                  // conversion tasks of one tile: G, X
@@ -60,18 +66,24 @@ __device__ __forceinline__ u32x4 lds_read_b128_any(unsigned addr) {
     return v;
 }
 
-template <int NQX>
+template <int NQX, int SW>
 __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) {
+    constexpr int XL = 8 * SW;                        // input columns one X task loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* const g_img = reinterpret_cast<unsigned short*>(smem_raw);               // [3][32][gp]
     unsigned short* const x_img = g_img + 3 * 32 * p.gp;                                      // [3][32][xp]
+    int* const toff_s = reinterpret_cast<int*>(x_img + 3 * 32 * p.xp);                        // [kW2MaxTaps]
     const unsigned g_base = (unsigned)(size_t)g_img, x_base = (unsigned)(size_t)x_img;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, g = lane >> 5;
     const int c0 = blockIdx.y * 32;
+    const int Cg = min(32, p.C - c0);                 // channels of this workgroup
+    const int nxt = Cg * p.PH * (p.PWp >> 3);         // its X conversion tasks per tile
+    const int ncol = p.T * Cg;                        // its GEMM columns: n = tap * Cg + channel
     const int TR = p.TR, PWp = p.PWp;
+    if (tid < kW2MaxTaps) toff_s[tid] = tid < p.T ? p.toff[tid] : 0;
     const int gplane = p.r_h * p.r_w, xplane = p.s_h * p.s_w;
 
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
@@ -103,9 +115,9 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         xt_f[q] = e % xfr;
         const int rr = e / xfr;
         xt_r[q] = rr % p.PH;
-        xt_c[q] = e < p.nxt ? rr / p.PH : -1;
+        xt_c[q] = e < nxt ? rr / p.PH : -1;
     }
-    float gr[8], xr[NQX][8];
+    float gr[8], xr[NQX][XL];
     auto load_tile = [&](int tile) {
         const int tq = tile % p.tiles_q;
         const int rest = tile / p.tiles_q;
@@ -120,14 +132,14 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
             for (int i = 0; i < 8; ++i)
                 gr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (ok && q + i < p.r_w) ? base + 4u * i : kOOB, 0, 0));
         }
-        const int h0 = r0 * p.sh + p.minh, w0 = q0 + p.minw;
+        const int h0 = r0 * p.sh + p.minh, w0 = q0 * SW + p.minw;
 #pragma unroll
         for (int q = 0; q < NQX; ++q) {
-            const int h = h0 + xt_r[q], w = w0 + 8 * xt_f[q];
-            const bool ok = xt_c[q] >= 0 && c0 + xt_c[q] < p.C && h >= 0 && h < p.s_h;
+            const int h = h0 + xt_r[q], w = w0 + XL * xt_f[q];
+            const bool ok = xt_c[q] >= 0 && h >= 0 && h < p.s_h;
             const unsigned base = (unsigned)(((b * p.C + c0 + xt_c[q]) * xplane + h * p.s_w + w) * 4);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < XL; ++i)
                 xr[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     x_rsrc, (ok && w + i >= 0 && w + i < p.s_w) ? base + 4u * i : kOOB, 0, 0));
         }
@@ -152,19 +164,39 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
     auto convert_tile = [&]() {
         if (gt_task) split_store(gr, g_img + gt_m * p.gp + gt_r * kW2TQ + 8 * gt_f, 32 * p.gp);
 #pragma unroll
-        for (int q = 0; q < NQX; ++q)
-            if (xt_c[q] >= 0) split_store(xr[q], x_img + xt_c[q] * p.xp + xt_r[q] * PWp + 8 * xt_f[q], 32 * p.xp);
+        for (int q = 0; q < NQX; ++q) {
+            if (xt_c[q] < 0) continue;
+            unsigned short* dst = x_img + xt_c[q] * p.xp + xt_r[q] * PWp + 8 * xt_f[q];
+            if constexpr (SW == 1) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = xr[q][i];
+                split_store(v, dst, 32 * p.xp);
+            } else {      // even input columns -> parity plane 0, odd -> plane 1 (PH * PWp elements further)
+                float ve[8], vo[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { ve[i] = xr[q][2 * i]; vo[i] = xr[q][2 * i + 1]; }
+                split_store(ve, dst, 32 * p.xp);
+                split_store(vo, dst + p.PH * PWp, 32 * p.xp);
+            }
+        }
     };
 
-    // this wave's column tiles: taps wave, wave + 8, ...
+    // this wave's column tiles: wave, wave + 8, ...; column n = tile * 32 + j <-> (tap n / Cg, channel n % Cg)
+    __syncthreads();                                   // toff_s
+    const int ntile = (ncol + 31) >> 5;
     unsigned boff[4];
+    int col_t[4], col_c[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int t = wave + kW2Waves * i;
-        boff[i] = t < p.T ? (unsigned)(2 * p.toff[t]) : 0u;
+        const int n = (wave + kW2Waves * i) * 32 + j;
+        const bool ok = n < ncol;
+        col_t[i] = ok ? n / Cg : -1;
+        col_c[i] = ok ? n - col_t[i] * Cg : 0;
+        boff[i] = ok ? 2u * (unsigned)(col_c[i] * p.xp + toff_s[col_t[i]]) : 0u;
     }
     const unsigned a_lane = g_base + 2u * (unsigned)(j * p.gp + 8 * g);
-    const unsigned b_lane = x_base + 2u * (unsigned)(j * p.xp + 8 * g);
+    const unsigned b_lane = x_base + 2u * (unsigned)(8 * g);
     const unsigned a_piece = 2u * 32u * (unsigned)p.gp, b_piece = 2u * 32u * (unsigned)p.xp;
 
     const int z = blockIdx.x, nz = gridDim.x;
@@ -175,7 +207,7 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         convert_tile();
         if (tile + nz < p.tiles_total) load_tile(tile + nz);
         __syncthreads();
-        if (wave < p.T)                     // (a wave without a column tile must not leave LDS reads in flight)
+        if (wave < ntile)                   // (a wave without a column tile must not leave LDS reads in flight)
         for (int kb = 0; kb < 2 * TR; ++kb) {
             const int r = kb >> 1, half = kb & 1;
             const unsigned ao = a_lane + 2u * (unsigned)(r * kW2TQ + half * 16);
@@ -183,7 +215,7 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
             const unsigned bo = b_lane + 2u * (unsigned)(r * p.sh * PWp + half * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (wave + kW2Waves * i >= p.T) break;                 // wave-uniform
+                if (wave + kW2Waves * i >= ntile) break;               // wave-uniform
                 u32x4 b0 = lds_read_b128_any(bo + boff[i]), b1 = lds_read_b128_any(bo + boff[i] + b_piece),
                       b2 = lds_read_b128_any(bo + boff[i] + 2 * b_piece);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
@@ -196,17 +228,16 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         }
     }
 
-    // ---- partial tile of this slice: out[z][m][(c0 + j) * T + t]
+    // ---- partial tile of this slice: out[z][m][(c0 + c) * T + t]
     const long CT = (long)p.C * p.T;
     float* const part = p.out + (long)z * p.M * CT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int t = wave + kW2Waves * i;
-        if (t >= p.T || c0 + j >= p.C) continue;
+        if (col_t[i] < 0) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 4 * g + (r & 3) + 8 * (r >> 2);
-            if (m < p.M) part[m * CT + (long)(c0 + j) * p.T + t] = acc[i][r];
+            if (m < p.M) part[m * CT + (long)(c0 + col_c[i]) * p.T + col_t[i]] = acc[i][r];
         }
     }
 }
@@ -227,36 +258,43 @@ struct W2XPlan {
 bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
     if (!w2x_enabled() || d->batch <= 0) return false;
     const int T = d->kh * d->kw;
-    if (d->c_out > 32 || (d->c_in & 15) || d->sw != 1 || T > kW2MaxTaps) return false;
+    if (d->c_out > 32 || (d->sw != 1 && d->sw != 2) || T > kW2MaxTaps) return false;
     const unsigned long long g_b = 4ull * d->batch * d->c_out * (unsigned long long)d->h_out * d->w_out;
     const unsigned long long x_b = 4ull * d->batch * d->c_in * (unsigned long long)d->h_in * d->w_in;
     if (!(g_b < 0x7fffffffull && x_b < 0x7fffffffull)) return false;
     *p = W2X{};
     p->B = d->batch; p->M = d->c_out; p->C = d->c_in; p->T = T;
     p->r_h = d->h_out; p->r_w = d->w_out; p->s_h = d->h_in; p->s_w = d->w_in;
-    p->sh = d->sh;
-    const int minh = -d->ph, minw = -d->pw;
+    p->sh = d->sh; p->sw = d->sw;
     const int span_h = (d->kh - 1) * d->dh, span_w = (d->kw - 1) * d->dw;
-    p->minh = minh; p->minw = minw;
+    p->minh = -d->ph; p->minw = -d->pw;
+    const int cg = d->c_in < 32 ? d->c_in : 32;          // channels of the fullest workgroup
     int TR = 4;
     while (TR > 1 && TR / 2 >= d->h_out) TR >>= 1;
     for (;; TR >>= 1) {
         p->TR = TR;
         p->tr_shift = __builtin_ctz(TR);
         p->PH = (TR - 1) * d->sh + span_h + 1;
-        p->PWp = (kW2TQ + span_w + 7) & ~7;
+        // row pitch of a (parity) plane: the farthest fragment starts at column 24 + span_w / sw
+        p->PWp = (kW2TQ + span_w / d->sw + 7) & ~7;
         p->gp = (TR * kW2TQ) | 8;                       // 16-byte slots per row image: odd -> lanes (rows) spread over the banks
-        p->xp = p->PH * p->PWp;
+        p->xp = d->sw * p->PH * p->PWp;
         if (((p->xp >> 3) & 1) == 0) p->xp += 8;
-        pl->lds = (size_t)3 * 32 * ((size_t)p->gp + p->xp) * 2;
+        pl->lds = (size_t)3 * 32 * ((size_t)p->gp + p->xp) * 2 + kW2MaxTaps * 4;
         p->ngt = 32 * TR * (kW2TQ / 8);
-        p->nxt = 32 * p->PH * (p->PWp >> 3);
-        if (pl->lds <= 160 * 1024 && p->ngt <= kW2Threads && p->nxt <= kW2Threads * 6) break;
+        p->nxt = cg * p->PH * (p->PWp >> 3);
+        if (pl->lds <= 160 * 1024 && p->ngt <= kW2Threads && p->nxt <= kW2Threads * (d->sw == 1 ? 6 : 3)) break;
         if (TR == 1) return false;
     }
     pl->nqx = p->nxt <= kW2Threads * 3 ? 3 : 6;
+    // element offset of a tap inside a channel image: patch row th*dh, patch column tw*dw (stride 2: parity plane
+    // (tw*dw) & 1, plane column (tw*dw) >> 1)
     for (int th = 0; th < d->kh; ++th)
-        for (int tw = 0; tw < d->kw; ++tw) p->toff[th * d->kw + tw] = th * d->dh * p->PWp + tw * d->dw;
+        for (int tw = 0; tw < d->kw; ++tw) {
+            const int ow = tw * d->dw;
+            p->toff[th * d->kw + tw] = d->sw == 1 ? th * d->dh * p->PWp + ow
+                                                  : (ow & 1) * p->PH * p->PWp + th * d->dh * p->PWp + (ow >> 1);
+        }
     p->tiles_r = rh_cdiv(d->h_out, TR);
     p->tiles_q = rh_cdiv(d->w_out, kW2TQ);
     const long tiles = (long)d->batch * p->tiles_r * p->tiles_q;
@@ -264,7 +302,7 @@ bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
     p->tiles_total = (int)tiles;
     pl->groups = rh_cdiv(d->c_in, 32);
     static const int z_env = [] { const char* e = getenv("RH_WGRAD2D_X6_SLICES"); return e ? atoi(e) : 0; }();
-    int Z = z_env > 0 ? z_env : 256 / pl->groups;       // one workgroup per CU (143 KB of LDS)
+    int Z = z_env > 0 ? z_env : 256 / pl->groups;       // one workgroup per CU (up to 143 KB of LDS)
     if (Z < 1) Z = 1;
     if (Z > tiles) Z = (int)tiles;
     pl->Z = Z;
@@ -303,8 +341,9 @@ int rh_wgrad2d_x6_launch(const rh_conv2d_desc* d, const float* dy, const float* 
         });
         rh_launch_main(kern, dim3((unsigned)pl.Z, (unsigned)pl.groups), dim3(kW2Threads), pl.lds, stream, p);
     };
-    if (pl.nqx == 3) go(wgrad2d_x6_kernel<3>);
-    else go(wgrad2d_x6_kernel<6>);
+    if (d->sw == 2) go(wgrad2d_x6_kernel<3, 2>);
+    else if (pl.nqx == 3) go(wgrad2d_x6_kernel<3, 1>);
+    else go(wgrad2d_x6_kernel<6, 1>);
     if (int e = rh_check_launch("wgrad2d_x6")) return e;
     *used = true;
     if (pl.Z > 1) return rh_reduce_partials_launch((const float*)ws, dw, nw, pl.Z, stream, "wgrad2d_x6_reduce");
