@@ -195,6 +195,9 @@ def main():
                     help="run the eager step instead of replaying the captured hipGraph (data-parallel runs record the "
                          "bucket all-reduces into the same graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-graph", action="store_true",
+                    help="discrete config: try to record the step into a hipGraph anyway (segfaults inside "
+                         "hipStreamEndCapture on ROCm 7.2: see the note at use_graph)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-products-leg", action="store_true",
                     help="skip the secondary forward_only_x3 / _x4 legs (3- / 4-partial-product measurement builds)")
@@ -250,8 +253,11 @@ def main():
     ddp.broadcast_module(m)
     use_ddp = world > 1 or force_dist
     # (the discrete config initialises its RVQ codebooks with k-means inside its first training step: host-driven,
-    # data-dependent work that a recorded graph cannot contain -- those steps run eagerly BEFORE the capture, below)
-    use_graph = not args.no_graph
+    # data-dependent work that a recorded graph cannot contain -- those steps run eagerly BEFORE the capture, below.
+    # Recording the whole discrete step still fails on this ROCm: hipStreamEndCapture segfaults inside the runtime although
+    # every component of the step -- RVQ, Encodec nets, torch.stft, MSD, the encoder -- captures and replays on its own,
+    # profiles/round4_discrete_capture_bisect.txt; so the discrete config runs eagerly unless --force-graph)
+    use_graph = not args.no_graph and (args.config != "discrete" or args.force_graph)
     gen_opt, dis_opt = m.configure_optimizers(capturable=use_graph)
     m.warmed_up = args.phase == "gan"
     m.skip_dead_grads = bool(args.skip_dead_grads)

@@ -58,15 +58,36 @@ __global__ __launch_bounds__(256) void conv2d_smallm_kernel(const SmallM2P p) {
     for (int c0 = 0; c0 < p.C; c0 += p.ck) {
         const int nc = min(p.ck, p.C - c0);
         __syncthreads();
-        // ---- the patch of this chunk: rows round-robin over the waves, lanes along W (coalesced, zero outside the plane)
-        for (int row = wave; row < nc * PHt; row += 4) {
-            const int c = row / PHt, pr = row - c * PHt;
-            const int gh = h0 + p.oh_min + pr;
-            const bool rok = gh >= 0 && gh < p.in_h;
-            const float* src = in + (((long)b * p.C + c0 + c) * p.in_h + gh) * p.in_w;
-            for (int pc = lane; pc < PW; pc += 64) {
-                const int gw = w0 + p.ow_min + pc;
-                patch[row * PW + pc] = (rok && gw >= 0 && gw < p.in_w) ? src[gw] : 0.f;
+        // ---- the patch of this chunk: rows round-robin over the waves, lanes along W (coalesced, zero outside the plane).
+        // U rows x 2 column passes are loaded before the first LDS store: one global-memory latency per 2 U elements (one
+        // element at a time the fill was latency-bound: 1.0 ms per first-layer data gradient, 7x both of its rooflines)
+        constexpr int U = 8;
+        const int rows = nc * PHt;
+        for (int row0 = wave; row0 < rows; row0 += 4 * U) {
+            float v[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + 4 * u;
+                const int c = row / PHt, pr = row - c * PHt;
+                const int gh = h0 + p.oh_min + pr;
+                const bool rok = row < rows && gh >= 0 && gh < p.in_h;
+                const float* src = in + (((long)b * p.C + c0 + c) * p.in_h + gh) * p.in_w;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int pc = lane + 64 * k;
+                    const int gw = w0 + p.ow_min + pc;
+                    v[u][k] = (rok && pc < PW && gw >= 0 && gw < p.in_w) ? src[gw] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + 4 * u;
+                if (row >= rows) break;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int pc = lane + 64 * k;
+                    if (pc < PW) patch[row * PW + pc] = v[u][k];
+                }
             }
         }
         // ---- and its weights, compact: the scalar loads this replaces (one 128-byte line per (tap, channel)) missed the
@@ -141,7 +162,7 @@ bool rh_conv2d_smallm_eligible(const rh_conv2d_desc* d, int which) {
     const long in_el = (long)d->batch * (which == 0 ? d->c_in : d->c_out) * (which == 0 ? (long)d->h_in * d->w_in : (long)d->h_out * d->w_out);
     const long out_el = (long)d->batch * M * (which == 0 ? (long)d->h_out * d->w_out : (long)d->h_in * d->w_in);
     const long tiles = (long)d->batch * rh_cdiv(which == 0 ? d->h_out : d->h_in, kSmTH) * rh_cdiv(which == 0 ? d->w_out : d->w_in, kSmTW);
-    return in_el < (1l << 40) && out_el < (1l << 40) && tiles < 0x7fffffffl && 64 + (d->kw - 1) * d->dw <= 256;
+    return in_el < (1l << 40) && out_el < (1l << 40) && tiles < 0x7fffffffl && 64 + (d->kw - 1) * d->dw <= 128;
 }
 
 // wp: the f32 section of the packed operand of that direction ([slot = th * kw + tw][c][Mp], Mp = 32)

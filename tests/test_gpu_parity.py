@@ -1132,7 +1132,8 @@ def test_discrete_spectral_training_step_golden(golden_dir, dev, tag, idx):
 # bf16x6 kernels (conv_x6_kernel.inc: every tile shape, split-K, batch folding at the short stages, the
 # phase-interleaved strided form, the per-phase transposed form) and the weight gradients at C = 768 / 1536 are
 # compared with the CPU oracle INSIDE the module graph, forward and backward.
-def _full_width_grads(dev, batch, x6_mode):
+def _full_width_grads(dev, batch, x6_mode, reparam_fused="0", gates=None):
+    """``gates``: a dict that receives the named gate log of the HIP run and the fp64 oracle's LeakyReLU masks."""
     import os
     from rave_amd import model as M
     cfg = O.v2_config()
@@ -1148,31 +1149,42 @@ def _full_width_grads(dev, batch, x6_mode):
     out = O.rave_forward(x, sdr, cfg, eps)
     torch.autograd.backward([out["y_raw"], out["y_mb"], out["reg"]], [cy_raw, cy_mb, torch.ones(())])
     sd64 = {k: (v.double().requires_grad_(not k.startswith("pqmf.")) if v.is_floating_point() else v) for k, v in sd.items()}
-    out64 = O.rave_forward(x.double(), sd64, cfg, eps.double())
+    from gate_flips import OracleGates, name_gate_log
+    with OracleGates() as og:
+        out64 = O.rave_forward(x.double(), sd64, cfg, eps.double())
     torch.autograd.backward([out64["y_raw"], out64["y_mb"], out64["reg"]],
                             [cy_raw.double(), cy_mb.double(), torch.ones((), dtype=torch.float64)])
     for k, v in sdr.items():
         v.grad64 = sd64[k].grad if torch.is_tensor(sd64[k]) and sd64[k].is_floating_point() else None
     # --- HIP path
     old = os.environ.get("RH_CONV_X6")
+    old_rp = os.environ.get("RH_REPARAM_FUSED")
     os.environ["RH_CONV_X6"] = x6_mode
+    os.environ["RH_REPARAM_FUSED"] = reparam_fused
     try:
+        from rave_amd import ops as R
         m = M.build_v2()
         m.load_state_dict(sd, strict=False)
         m = m.to(dev).train()
         m.prepare_weights()
+        if gates is not None:
+            R.gate_log_begin()
         zp, x_mb = m.encode(x.to(dev), return_mb=True)
         z, reg = m.encoder.reparametrize(zp, eps.to(dev))
         y_mb = m.decoder(z)
+        if gates is not None:
+            gates["log"] = name_gate_log(R.gate_log_end(), m)      # (the decoder runs again below: same gates, logged once)
+            gates["oracle64"] = og.masks
         y_raw = m.decode(z)
         torch.autograd.backward([y_raw, y_mb, reg], [cy_raw.to(dev), cy_mb.to(dev), torch.ones((), device=dev)])
         m.release_weights()
         torch.cuda.synchronize()
     finally:
-        if old is None:
-            os.environ.pop("RH_CONV_X6", None)
-        else:
-            os.environ["RH_CONV_X6"] = old
+        for key, val in (("RH_CONV_X6", old), ("RH_REPARAM_FUSED", old_rp)):
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
     return m, sdr, out, dict(x_mb=x_mb, z_params=zp, y_mb=y_mb, y_raw=y_raw)
 
 
@@ -1205,6 +1217,41 @@ def test_v2_full_width_hot_path_forward_backward_vs_oracle(dev, x6_mode):
         checked += 1
     assert checked == 112, checked          # 56 weight-normalised convs x (g, v)
     assert worst > 0.0
+
+
+def test_v2_full_width_with_the_fused_reparametrisation_gate_flips_counted(dev):
+    """The DEFAULT reparametrisation (rh_reparam_*_f32: softplus / KL / noise on two HIP launches instead of ~30 ATen ones)
+    produces latents that differ from the ATen chain's in the last bit.  Round 3 kept it opt-in because on this fixture
+    three weight-gradient tensors then leave the strict bound of the test above; VERDICT r3 #7: make it the default "once
+    1(a) explains its three tensors".  Here the gates are COUNTED (tests/gate_flips.py): every gradient outside the tight
+    bound lies upstream of a LeakyReLU gate whose pre-activation changed sign against the fp64 evaluation, and stays within
+    the few-flip bound; outputs keep the 1e-4 bar."""
+    from gate_flips import chain_flips, flips_downstream_by_param
+    g = {}
+    m, sdr, ref, got = _full_width_grads(dev, 2, "1", reparam_fused="1", gates=g)
+    assert rel_l2(got["x_mb"], ref["x_mb"]) < TOL_OP
+    for k in ("z_params", "y_mb", "y_raw"):
+        assert rel_l2(got[k], ref[k]) < TOL_E2E, k
+    flips, n_gates, worst_mag = chain_flips(g["log"], g["oracle64"])
+    down = flips_downstream_by_param(g["log"], flips)
+    named = dict(m.named_parameters())
+    outside, checked = [], 0
+    for k, v in sdr.items():
+        if not (k.startswith("encoder.") or k.startswith("decoder.")) or v.grad is None:
+            continue
+        ref_err = rel_l2(v.grad, v.grad64)
+        err = rel_l2(named[k].grad, v.grad64)
+        tol = 1e-3 if k.endswith("weight_g") else 2e-4
+        if err >= max(tol, 3.0 * ref_err):
+            outside.append((k, err, ref_err, down[k]))
+        assert err < 5e-3, (k, err, ref_err)
+        checked += 1
+    print(f"fused reparametrisation: gate flips vs fp64 {sum(flips)} of {n_gates} (largest flipped |pre-activation| {worst_mag:.1e} x rms); "
+          f"outside the tight bound: {[(k, '%.1e' % e, d) for k, e, _, d in outside]}")
+    assert checked == 112
+    assert sum(flips) <= 1e-4 * n_gates and worst_mag < 1e-3
+    for k, err, ref_err, d in outside:
+        assert d >= 1, (k, err, ref_err, "outside the tight bound without a flipped gate downstream")
 
 
 def test_v2_full_width_x6_kernels_are_the_ones_that_ran(dev):

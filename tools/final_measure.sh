@@ -7,6 +7,13 @@ has() { [ "$PARTS" = all ] || echo " $PARTS " | grep -q " $1 "; }
 if has probes; then      # (binaries: bash tools/probe/build.sh in the build container)
   timeout 120 tools/probe/_var/mfma_clock > $O/probe_mfma_clock.txt 2>&1
   timeout 60 tools/probe/_var/tr_read > $O/probe_tr_read.txt 2>&1
+  timeout 60 tools/probe/_var/lds_unaligned > $O/probe_lds_unaligned.txt 2>&1
+fi
+if has products; then    # 3 / 4 bf16 partial products against the 6-product kernels and the CPU oracle (tools/x6_products.py)
+  timeout 600 python tools/x6_products.py --md $O/x6_products.md > $O/x6_products.log 2>&1
+fi
+if has refstep; then     # the unmodified reference training_step on the drop-ins (needs tools/run_reference_step.sh stage)
+  [ -d oracle/_ref/reference/rave ] && timeout 600 python tools/run_reference_step.py > $O/reference_step.log 2>&1
 fi
 if has bench; then
   timeout 400 python bench.py --steps 20 --warmup 5 < /dev/null > $O/bench_n1.log 2>&1
@@ -16,8 +23,8 @@ fi
 if has others; then
   timeout 300 python bench.py --phase gan --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_gan.log 2>&1
   timeout 300 python bench.py --phase gan --skip-dead-grads --steps 8 --warmup 4 --no-cpu-baseline --no-kernel-timing < /dev/null > $O/bench_gan_skip.log 2>&1
-  timeout 300 python bench.py --config discrete --phase gan --batch 32 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_discrete.log 2>&1
-  timeout 300 python bench.py --config v3 --phase gan --batch 16 --steps 4 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_v3.log 2>&1
+  timeout 300 python bench.py --config discrete --phase gan --batch 32 --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_discrete.log 2>&1
+  timeout 300 python bench.py --config v3 --phase gan --batch 16 --steps 8 --warmup 4 --no-cpu-baseline < /dev/null > $O/bench_v3.log 2>&1
 fi
 if has layers; then
   timeout 200 python tools/bench_layers.py < /dev/null > $O/layers.log 2>&1
