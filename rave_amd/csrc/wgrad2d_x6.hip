@@ -39,7 +39,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int kW2Waves = 8, kW2Threads = 512;
-constexpr int kW2TQ = 32;          // output columns per tile = two K blocks
+constexpr int kW2Pos = 128;        // output positions per tile = 8 K blocks: TR rows x TQ columns, TQ in {8, 16, 32}
 constexpr int kW2MaxTaps = 32;     // 4 column tiles per wave x 8 waves
 
 struct W2X {
@@ -50,6 +50,7 @@ struct W2X {
     int r_h, r_w, s_h, s_w;
     int sh;                        // stride along H (1 along W)
     int TR, tr_shift;              // output rows per tile (power of two)
+    int TQ, tq_shift;              // output columns per tile: 32, or 16 / 8 on narrow planes (more rows instead)
     int tiles_r, tiles_q, tiles_total;
     int PH, PWp;                   // staged patch rows, row pitch in elements (multiple of 8; per parity plane at stride 2)
     int sw;                        // stride along W: 1, or 2 (two parity planes per channel image)
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
 
     // ---- conversion tasks (tile-invariant part).  G: (row m, tile row, 8-column fragment) -- one per thread at TR = 4;
     // X: (channel, patch row, 8-column fragment), NQX per thread
-    const int gfr = kW2TQ / 8;                       // fragments per G tile row
+    const int TQ = p.TQ;
+    const int gfr = TQ >> 3;                         // fragments per G tile row
     const int xfr = PWp >> 3;                        // fragments per patch row
     int gt_m, gt_r, gt_f;
     {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         const int rest = tile / p.tiles_q;
         const int tr = rest % p.tiles_r;
         const int b = rest / p.tiles_r;
-        const int r0 = tr * TR, q0 = tq * kW2TQ;
+        const int r0 = tr * TR, q0 = tq * TQ;
         {   // G fragment: row r0 + gt_r, columns q0 + 8 f .. + 7, zero beyond the output plane
             const int r = r0 + gt_r, q = q0 + 8 * gt_f;
             const bool ok = gt_task && gt_m < p.M && r < p.r_h;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         }
     };
     auto convert_tile = [&]() {
-        if (gt_task) split_store(gr, g_img + gt_m * p.gp + gt_r * kW2TQ + 8 * gt_f, 32 * p.gp);
+        if (gt_task) split_store(gr, g_img + gt_m * p.gp + gt_r * TQ + 8 * gt_f, 32 * p.gp);
 #pragma unroll
         for (int q = 0; q < NQX; ++q) {
             if (xt_c[q] < 0) continue;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         boff[i] = ok ? 2u * (unsigned)(col_c[i] * p.xp + toff_s[col_t[i]]) : 0u;
     }
     const unsigned a_lane = g_base + 2u * (unsigned)(j * p.gp + 8 * g);
-    const unsigned b_lane = x_base + 2u * (unsigned)(8 * g);
+    const int nkb = (TR * TQ) >> 4;
     const unsigned a_piece = 2u * 32u * (unsigned)p.gp, b_piece = 2u * 32u * (unsigned)p.xp;
 
     const int z = blockIdx.x, nz = gridDim.x;
@@ -208,11 +210,13 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
         if (tile + nz < p.tiles_total) load_tile(tile + nz);
         __syncthreads();
         if (wave < ntile)                   // (a wave without a column tile must not leave LDS reads in flight)
-        for (int kb = 0; kb < 2 * TR; ++kb) {
-            const int r = kb >> 1, half = kb & 1;
-            const unsigned ao = a_lane + 2u * (unsigned)(r * kW2TQ + half * 16);
+        for (int kb = 0; kb < nkb; ++kb) {
+            // K block kb = tile positions 16 kb .. 16 kb + 15 (row-major over TR x TQ); this lane's fragment starts at
+            // position 16 kb + 8 g = (row, column) of the tile -- a fragment never straddles a row (TQ is a multiple of 8)
+            const unsigned ao = a_lane + 2u * (unsigned)(16 * kb);
             u32x4 a0 = lds_read_b128_any(ao), a1 = lds_read_b128_any(ao + a_piece), a2 = lds_read_b128_any(ao + 2 * a_piece);
-            const unsigned bo = b_lane + 2u * (unsigned)(r * p.sh * PWp + half * 16);
+            const int pos = 16 * kb + 8 * g;
+            const unsigned bo = x_base + 2u * (unsigned)((pos >> p.tq_shift) * p.sh * PWp + (pos & (TQ - 1)));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (wave + kW2Waves * i >= ntile) break;               // wave-uniform
@@ -269,19 +273,23 @@ bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
     const int span_h = (d->kh - 1) * d->dh, span_w = (d->kw - 1) * d->dw;
     p->minh = -d->ph; p->minw = -d->pw;
     const int cg = d->c_in < 32 ? d->c_in : 32;          // channels of the fullest workgroup
-    int TR = 4;
+    // tile = TR x TQ output positions, 128 where the plane allows: TQ = 32 columns, or 16 / 8 on narrow planes (descript
+    // MRD bands shrink to 8 columns) with correspondingly more rows
+    int TQ = 32;
+    while (TQ > 8 && TQ / 2 >= d->w_out) TQ >>= 1;
+    int TR = kW2Pos / TQ;
     while (TR > 1 && TR / 2 >= d->h_out) TR >>= 1;
     for (;; TR >>= 1) {
-        p->TR = TR;
-        p->tr_shift = __builtin_ctz(TR);
+        p->TR = TR; p->TQ = TQ;
+        p->tr_shift = __builtin_ctz(TR); p->tq_shift = __builtin_ctz(TQ);
         p->PH = (TR - 1) * d->sh + span_h + 1;
-        // row pitch of a (parity) plane: the farthest fragment starts at column 24 + span_w / sw
-        p->PWp = (kW2TQ + span_w / d->sw + 7) & ~7;
-        p->gp = (TR * kW2TQ) | 8;                       // 16-byte slots per row image: odd -> lanes (rows) spread over the banks
+        // row pitch of a (parity) plane: the farthest fragment starts at column TQ - 8 + span_w / sw
+        p->PWp = (TQ + span_w / d->sw + 7) & ~7;
+        p->gp = (TR * TQ) | 8;                          // 16-byte slots per row image: odd -> lanes (rows) spread over the banks
         p->xp = d->sw * p->PH * p->PWp;
         if (((p->xp >> 3) & 1) == 0) p->xp += 8;
         pl->lds = (size_t)3 * 32 * ((size_t)p->gp + p->xp) * 2 + kW2MaxTaps * 4;
-        p->ngt = 32 * TR * (kW2TQ / 8);
+        p->ngt = 32 * TR * (TQ / 8);
         p->nxt = cg * p->PH * (p->PWp >> 3);
         if (pl->lds <= 160 * 1024 && p->ngt <= kW2Threads && p->nxt <= kW2Threads * (d->sw == 1 ? 6 : 3)) break;
         if (TR == 1) return false;
@@ -296,7 +304,7 @@ bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
                                                   : (ow & 1) * p->PH * p->PWp + th * d->dh * p->PWp + (ow >> 1);
         }
     p->tiles_r = rh_cdiv(d->h_out, TR);
-    p->tiles_q = rh_cdiv(d->w_out, kW2TQ);
+    p->tiles_q = rh_cdiv(d->w_out, p->TQ);
     const long tiles = (long)d->batch * p->tiles_r * p->tiles_q;
     if (tiles >= 0x7fffffffl) return false;
     p->tiles_total = (int)tiles;

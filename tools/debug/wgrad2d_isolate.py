@@ -13,6 +13,10 @@ CASES = [
     (2, 6, 7, 19, 23, (4, 3), (3, 2), (2, 2), (3, 2)),
     (4, 2, 32, 2049, 61, (9, 3), (1, 1), (1, 1), (4, 1)),         # full-size first layer
     (4, 32, 32, 129, 256, (3, 9), (1, 2), (1, 1), (1, 4)),
+    (4, 32, 32, 513, 16, (3, 9), (1, 2), (1, 1), (1, 4)),         # narrow MRD bands: 8 / 16 output columns per row
+    (4, 32, 32, 513, 8, (3, 3), (1, 1), (1, 1), (1, 1)),
+    (4, 32, 32, 257, 32, (3, 9), (1, 2), (1, 1), (1, 4)),
+    (2, 16, 16, 9, 1, (3, 1), (1, 1), (1, 1), (1, 0)),
 ]
 if len(sys.argv) > 2 and sys.argv[1] == "worker":
     sys.path.insert(0, ROOT)
