@@ -234,6 +234,12 @@ int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_
 /* g = dy * act'(y) for an OUTPUT LeakyReLU (sign(y) == sign(pre-activation)): the cotangent the backward
  * entry points of a conv with out_act expect. */
 int rh_act_bwd_f32(const float* dy, const float* y, int32_t act, float slope, int64_t n, float* g, rh_stream_t stream);
+/* One pass for the backward prologue of a conv with a LeakyReLU on its OUTPUT (rave/discriminator.py:50,
+ * rave/descript_discriminator.py:27): g = dy * act'(y) and dbias[m] = sum over (batch, plane) of g, on (B, M, plane)
+ * tensors; ordered partial sums (deterministic).  workspace: rh_act_bwd_bias_workspace_bytes(M) bytes. */
+int64_t rh_act_bwd_bias_workspace_bytes(int32_t M);
+int rh_act_bwd_bias_f32(const float* dy, const float* y, int32_t act, float slope, int32_t B, int32_t M, int64_t plane, float* g,
+                        float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream);
 /* nn.functional.avg_pool1d(x, 2) of MultiScaleDiscriminator (rave/discriminator.py:135). */
 int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
 int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);

@@ -100,6 +100,8 @@ def _load() -> C.CDLL:
         "rh_amp_tanh_bwd_f32": ([P, P, I32, I32, I32, P, P], C.c_int),
         "rh_act_fwd_f32": ([P, P, I32, F, I32, I32, I32, P, P], C.c_int),
         "rh_act_bwd_f32": ([P, P, I32, F, I64, P, P], C.c_int),
+        "rh_act_bwd_bias_workspace_bytes": ([I32], I64),
+        "rh_act_bwd_bias_f32": ([P, P, I32, F, I32, I32, I64, P, P, P, I64, P], C.c_int),
         "rh_snake_bwd_workspace_bytes": ([I32, I32], I64),
         "rh_snake_bwd_f32": ([P, P, P, I32, I32, I32, P, P, P, I64, P], C.c_int),
         "rh_stft_frame_fwd_f32": ([P, P, I64, I32, I32, I32, I32, P, P], C.c_int),

@@ -244,12 +244,15 @@ __device__ __forceinline__ void emit_fragment(const float (&v)[8], unsigned* dst
     }
 }
 
-__device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds /* [kPackSlots][32][33] */) {
+// (sg, sn): this workgroup takes the slot groups sg, sg + sn, ... of the tile -- a conv with ONE 32 x 32 tile and 27 taps
+// (the 2-D discriminator layers) otherwise packs all its slots serially in one workgroup: 36 us per layer, 108 layers per
+// v3 step
+__device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds /* [kPackSlots][32][33] */, int sg = 0, int sn = 1) {
     const int ct = (q.C + 31) / 32;
     const int c0 = (int)(tile % ct) * 32;
     const int m0 = (int)(tile / ct) * 32;
     const int tid = threadIdx.x;
-    for (int s0 = 0; s0 < q.nslots; s0 += kPackSlots) {
+    for (int s0 = sg * kPackSlots; s0 < q.nslots; s0 += sn * kPackSlots) {
         const int ns = min(kPackSlots, q.nslots - s0);
         for (int e = tid; e < ns * 1024; e += 256) {
             const int sl = e % ns;
@@ -341,8 +344,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackP a, const PackP b)
     __shared__ float lds[kPackSlots * 32 * 33];
     const long t = blockIdx.x;
     const long na = pack_tiles(a);
-    if (t < na) pack_tile(a, t, lds);
-    else if (t - na < pack_tiles(b)) pack_tile(b, t - na, lds);
+    if (t < na) pack_tile(a, t, lds, blockIdx.y, gridDim.y);
+    else if (t - na < pack_tiles(b)) pack_tile(b, t - na, lds, blockIdx.y, gridDim.y);
+}
+
+// slot groups of one pack launch spread over grid.y when the launch has few tiles (<= 8 groups)
+inline unsigned pack_slot_groups(const PackP& a, const PackP& b, long tiles) {
+    if (tiles >= 64) return 1;
+    const int ns = a.nslots > b.nslots ? a.nslots : b.nslots;
+    const int g = (ns + kPackSlots - 1) / kPackSlots;
+    return (unsigned)(g < 1 ? 1 : (g > 8 ? 8 : g));
 }
 
 int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* scale, float* wp, PackP* p) {
@@ -407,7 +418,7 @@ int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float
     if (int e = fill_pack(d, 1, w, scale, wp_bwd, &b)) return e;
     const long tiles = pack_tiles(a) + pack_tiles(b);
     if (tiles == 0) return RH_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a, b);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles, pack_slot_groups(a, b, tiles)), dim3(256), 0, stream, a, b);
     return rh_check_launch("conv1d_pack");
 }
 
@@ -416,7 +427,7 @@ int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float
 int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what) {
     const long tiles = pack_tiles(a) + pack_tiles(b);
     if (tiles == 0) return RH_OK;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a, b);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles, pack_slot_groups(a, b, tiles)), dim3(256), 0, stream, a, b);
     return rh_check_launch(what);
 }
 

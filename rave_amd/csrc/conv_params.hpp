@@ -124,7 +124,7 @@ int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const cha
 // (rh_bias_grad_workspace(M) bytes) + ordered finalize -> deterministic
 int64_t rh_bias_grad_workspace(int M);
 int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db, int B, int M, long plane, int act,
-                        float slope, hipStream_t stream);
+                        float slope, hipStream_t stream, float* g_out = nullptr);
 int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what);
 
 int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p);

@@ -173,9 +173,11 @@ static void reduce_partials_go(const float* part, float* out, long n, int Z, hip
 // of the (b, plane) index space, then an ordered pass over the slices (deterministic).
 constexpr int kBiasSlices = 64;
 
+// g_out (optional): the same pass also WRITES g = dy * act'(y) -- the operand the data- and weight-gradient kernels of a
+// conv with an output activation take -- so that one sweep replaces act_bwd_kernel (dy, y -> g) + this kernel (g -> sums).
 __global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           float* __restrict__ part, int B, int M, long plane, int act,
-                                                          float slope) {
+                                                          float slope, float* __restrict__ g_out) {
     __shared__ float red[4];
     const int m = blockIdx.x, sl = blockIdx.y;
     const long segs_per_b = (plane + 1023) / 1024;
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restric
             if (e < plane) {
                 float v = dy[base + e];
                 if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
+                if (g_out) g_out[base + e] = v;
                 s += v;
             }
         }
@@ -704,9 +707,22 @@ int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipS
 int64_t rh_bias_grad_workspace(int M) { return (int64_t)M * kBiasSlices * (int64_t)sizeof(float); }
 
 int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db, int B, int M, long plane, int act,
-                        float slope, hipStream_t stream) {
-    hipLaunchKernelGGL(bias_grad2d_kernel, dim3(M, kBiasSlices), dim3(256), 0, stream, dy, y, part, B, M, plane, act, slope);
+                        float slope, hipStream_t stream, float* g_out) {
+    hipLaunchKernelGGL(bias_grad2d_kernel, dim3(M, kBiasSlices), dim3(256), 0, stream, dy, y, part, B, M, plane, act, slope, g_out);
     if (int e = rh_check_launch("bias_grad")) return e;
     hipLaunchKernelGGL(bias_grad2d_finalize_kernel, dim3(rh_cdiv(M, 64)), dim3(64), 0, stream, (const float*)part, db, M);
     return rh_check_launch("bias_grad_finalize");
+}
+
+// g = dy * act'(y) AND dbias[m] = sum_{b, plane} g in one pass over (B, M, plane) tensors (ordered partials: deterministic):
+// the backward prologue of a conv whose LeakyReLU sits on its OUTPUT (rave/discriminator.py:50,
+// rave/descript_discriminator.py:27).  workspace: rh_act_bwd_bias_workspace_bytes(M).
+extern "C" int64_t rh_act_bwd_bias_workspace_bytes(int32_t M) { return rh_bias_grad_workspace(M); }
+extern "C" int rh_act_bwd_bias_f32(const float* dy, const float* y, int32_t act, float slope, int32_t B, int32_t M, int64_t plane,
+                                   float* g, float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    RH_REQUIRE(dy && y && g && dbias && B >= 0 && M > 0 && plane > 0, RH_ERR_INVALID, "act_bwd_bias: bad arguments");
+    RH_REQUIRE(act == RH_ACT_NONE || act == RH_ACT_LEAKY, RH_ERR_UNSUPPORTED, "act_bwd_bias: activation must be none or leaky");
+    RH_REQUIRE(workspace && workspace_bytes >= rh_bias_grad_workspace(M), RH_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
+    if (B == 0) return hipMemsetAsync(dbias, 0, (size_t)M * sizeof(float), (hipStream_t)stream) == hipSuccess ? RH_OK : RH_ERR_INVALID;
+    return rh_bias_grad_launch(dy, y, (float*)workspace, dbias, B, M, plane, act, slope, (hipStream_t)stream, g);
 }

@@ -111,20 +111,29 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
     if (tid == 0 && loss_part) loss_part[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
 }
 
-// one block per code: count and ordered vector sum of the vectors assigned to it, then the EMAs
+// one block per code: count and ordered vector sum of the vectors assigned to it, then the EMAs.
+// The scan over the N indices goes 64 at a time (one coalesced load + a ballot per wave) and only the hits -- N / K = 1 on
+// average -- touch x, in ascending n: the same sums in the same order as a serial scan.  (The serial scan, one dependent
+// 8-byte load per vector, took 395 us per quantiser: 6.3 ms of the 131 ms discrete step for 1024 vectors.)
 __global__ __launch_bounds__(128) void vq_ema_kernel(const float* __restrict__ x, const long long* __restrict__ ind,
                                                      int N, int D, float decay, float* __restrict__ cluster_size,
                                                      float* __restrict__ embed_avg) {
     const int k = blockIdx.x;
+    const int lane = threadIdx.x & 63;
     int count = 0;
     for (int d0 = 0; d0 < D; d0 += 128) {
         const int d = d0 + threadIdx.x;
         float s = 0.f;
         int c = 0;
-        for (int n = 0; n < N; ++n) {
-            if (ind[n] == k) {
-                ++c;
-                if (d < D) s += x[(long)n * D + d];
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            const int n = n0 + lane;
+            const bool hit = n < N && ind[n] == k;
+            unsigned long long mask = __ballot(hit);
+            c += __popcll(mask);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                if (d < D) s += x[(long)(n0 + b) * D + d];
             }
         }
         count = c;

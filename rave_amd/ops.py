@@ -765,11 +765,20 @@ class _Conv2dFn(torch.autograd.Function):
         dy = _chk(dy, "dy")
         s = L.stream()
         dx = dw = db = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if y is not None:
-            # one elementwise pass forms dy * act'(y); the gradient kernels then run activation-free
-            # (which lets the data gradient use the LDS-DMA pipeline: DMA cannot transform data in flight)
+            # one elementwise pass forms dy * act'(y); the gradient kernels then run activation-free.  With a bias the SAME
+            # pass also reduces the bias gradient (rh_act_bwd_bias_f32: one sweep instead of act_bwd + bias_grad)
             g = torch.empty_like(dy)
-            L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y), d.act, d.act_slope, dy.numel(), L.ptr(g), s), "act_bwd")
+            if need_b:
+                db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
+                nb = L.lib.rh_act_bwd_bias_workspace_bytes(d.c_out)
+                wsb = torch.empty(max(nb, 4) // 4, device=dy.device, dtype=torch.float32)
+                L.check(L.lib.rh_act_bwd_bias_f32(L.ptr(dy), L.ptr(y), d.act, d.act_slope, d.batch, d.c_out, d.h_out * d.w_out,
+                                                  L.ptr(g), L.ptr(db), L.ptr(wsb), nb, s), "act_bwd_bias")
+                need_b = False
+            else:
+                L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y), d.act, d.act_slope, dy.numel(), L.ptr(g), s), "act_bwd")
             dy, y = g, None
             d = L.Conv2dDesc.from_buffer_copy(d)
             d.act = ACT_NONE
@@ -778,7 +787,6 @@ class _Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.check(_launch2("conv2d_dgrad", d, lambda: L.lib.rh_conv2d_bwd_data_f32(
                 dref, L.ptr(dy), L.ptr(y), L.ptr(wp_b), L.ptr(dx), s)), "conv2d_bwd_data")
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or need_b:
             dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
             if need_b:
@@ -786,7 +794,8 @@ class _Conv2dFn(torch.autograd.Function):
             nbytes = L.lib.rh_conv2d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
             L.check(_launch2("conv2d_wgrad", d, lambda: L.lib.rh_conv2d_bwd_weight_f32(
-                dref, L.ptr(dy), L.ptr(y), L.ptr(x), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes, s)), "conv2d_bwd_weight")
+                dref, L.ptr(dy), L.ptr(y), L.ptr(x), L.ptr(dw), L.ptr(db) if need_b else None, L.ptr(ws), nbytes, s)),
+                "conv2d_bwd_weight")
         return dx, dw, db, None, None, None, None, None
 
 
