@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librave_hip.so")
-SOURCES = ["api.cpp", "pqmf.hip", "pqmf_fold.hip", "pqmf_fold2.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_x6.hip", "conv_x6_is1.hip", "conv_x6_is2.hip", "conv_x6_is4.hip", "unit_x6.hip", "conv_host.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "conv_smallc.hip", "conv2d.hip", "conv2d_x6.hip", "conv2d_smallm.hip", "wgrad2d_x6.hip", "vq.hip", "feed.hip", "misc.hip", "stft_loss.hip", "adam.hip", "feature_match.hip"]
+SOURCES = ["api.cpp", "pqmf.hip", "pqmf_fold.hip", "pqmf_fold2.hip", "conv_igemm.hip", "conv_igemm_dma.hip", "conv_x6.hip", "conv_x6_is1.hip", "conv_x6_is2.hip", "conv_x6_is4.hip", "unit_x6.hip", "conv_host.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "conv_smallc.hip", "conv2d.hip", "conv2d_x6.hip", "conv2d_smallm.hip", "conv2d_smallc.hip", "wgrad2d_x6.hip", "vq.hip", "feed.hip", "misc.hip", "stft_loss.hip", "adam.hip", "feature_match.hip"]
 HEADERS = ["common.hpp", "conv_params.hpp", "conv2d_x6.hpp", "conv_x6_kernel.inc", os.path.join("..", "..", "include", "rave_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

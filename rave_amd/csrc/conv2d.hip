@@ -25,6 +25,11 @@ bool rh_conv2d_smallm_eligible(const rh_conv2d_desc* d, int which);
 int rh_conv2d_smallm_launch(const rh_conv2d_desc* d, int which, const float* in, const float* wp, const float* bias, float* out,
                             hipStream_t stream);
 
+// conv2d_smallc.hip: vector-ALU forward for <= 4 input channels (the first conv of the spectral discriminators' stacks)
+bool rh_conv2d_smallc_fwd_eligible(const rh_conv2d_desc* d);
+int rh_conv2d_smallc_fwd_launch(const rh_conv2d_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y,
+                                hipStream_t stream);
+
 namespace {
 
 constexpr int kPh2 = 8;   // max sh*sw
@@ -1191,7 +1196,7 @@ extern "C" int rh_conv2d_plan_info(const rh_conv2d_desc* d, int32_t which, int64
     for (int i = 0; i < 16; ++i) out[i] = 0;
     rh_conv2d_desc dd = *d;
     if (which == 1) dd.act = RH_ACT_NONE;              // (the data gradient sees dy with act'(y) folded in)
-    if (rh_conv2d_smallm_eligible(&dd, which)) { out[0] = 2; return RH_OK; }
+    if (rh_conv2d_smallm_eligible(&dd, which) || (which == 0 && rh_conv2d_smallc_fwd_eligible(d))) { out[0] = 2; return RH_OK; }
     Plan2 t;
     build_plan2(d, which, &t);
     C2X q;
@@ -1257,6 +1262,7 @@ extern "C" int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const 
     p.mul_act = RH_ACT_NONE; p.mul_slope = 0.f;
     p.epi_act = d->act; p.epi_slope = d->act_slope;
     if (rh_conv2d_smallm_eligible(d, 0)) return rh_conv2d_smallm_launch(d, 0, x, wp_fwd, bias, y, (hipStream_t)stream);
+    if (rh_conv2d_smallc_fwd_eligible(d)) return rh_conv2d_smallc_fwd_launch(d, x, wp_fwd, bias, y, (hipStream_t)stream);
     {   // exact f32 on the bf16 matrix cores where the geometry allows (C in blocks of 16): conv2d_x6.hip
         C2X q;
         fill_c2x(t, d->c_in, d->c_out, wp_fwd, &q);

@@ -637,7 +637,7 @@ extern "C" int rh_conv1d_kernel_family(const rh_conv1d_desc* d, int which, int h
     p.add = has_add ? dummy : nullptr;
     p.mul_src = (which == 1 && d->act != RH_ACT_NONE) ? dummy : nullptr;
     if (p.B <= 0 || p.ncols <= 0 || p.M <= 0 || !rh_conv_dma_eligible(p)) return 0;
-    return rh_conv_x6_workspace(p) >= 0 ? 1 : 0;
+    return (rh_conv_x6_workspace(p) >= 0 || rh_conv_c2x_query(p)) ? 1 : 0;
 }
 
 // Diagnostics: out8 = {family (rh_conv1d_kernel_family), tm, tn, wm, K slices, fragment-layout input stride, virtual rows, workgroups}

@@ -538,6 +538,8 @@ int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws,
         bool used = false;
         if (int e = rh_conv_launch_x6(p, stream, what, ws, ws_bytes, &used)) return e;
         if (used) return RH_OK;
+        if (int e = rh_conv_launch_c2x(p, stream, what, &used)) return e;      // stride-3 gathers: 2-D kernel, W = 1
+        if (used) return RH_OK;
     }
     if (p.M <= 32) return launch_dma<1, 2, 1, 4>(p, stream, what, ws, ws_bytes);
     if (p.M <= 64) return launch_dma<2, 1, 1, 4>(p, stream, what, ws, ws_bytes);

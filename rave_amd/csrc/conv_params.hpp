@@ -140,12 +140,19 @@ int64_t rh_conv_x6_workspace(ConvP p);         // bf16x6 path: scratch it needs,
 // strided gather (one phase, contiguous taps, dilation 1).
 inline int rh_x6_mode(int C, int nphase, int is, int inner, int ntaps0, const int* off, const int* kk) {
     if (is == 1) return (C & 15) == 0 ? 1 : 0;
+    // stride 3 (descript MPD's (5,1) stride-(3,1) convolutions, rave/descript_discriminator.py:36-42): plain-tap fragments
+    // as for stride 1; conv_x6_kernel has no stride-3 instance (3 does not divide the 8-sample octet) -- the launcher hands
+    // these geometries to the 2-D kernel (conv2d_x6.hip, W = 1), where a stride is a multiplier on the lane's patch position
+    if (is == 3) return (nphase == 1 && inner == 1 && (C & 15) == 0) ? 1 : 0;
     if (nphase != 1 || inner != 1 || (is != 2 && is != 4) || (C * is) % 16 != 0) return 0;
     for (int t = 0; t < ntaps0; ++t)
         if (off[t] != off[0] + t || kk[t] != t) return 0;
     return is;
 }
 int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool* used);
+// stride-3 gathers with plain-tap fragments on the 2-D bf16x6 kernel (conv2d_x6.hip); query = would this launch take it?
+int rh_conv_launch_c2x(ConvP& p, hipStream_t stream, const char* what, bool* used);
+bool rh_conv_c2x_query(ConvP p);
 bool rh_conv_x6_plan_query(ConvP p, int* out7);
 
 // Vector-ALU kernels for the 1- / 2-channel first layers of the discriminators (conv_smallc.hip)

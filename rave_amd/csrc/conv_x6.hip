@@ -1,6 +1,7 @@
 // Host side of the bf16x6 convolution path (kernels: conv_x6_kernel.inc): tile / split-K plan and launch.
 #include <cstdlib>
 #include "conv_params.hpp"
+#include "conv2d_x6.hpp"
 
 void rh_x6_dispatch_is1(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
 void rh_x6_dispatch_is2(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
@@ -219,4 +220,44 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
         return rh_splitk_finalize_launch(f, stream);
     }
     return RH_OK;
+}
+
+// ---- stride-3 1-D gathers on the 2-D kernel (conv2d_x6.hip): the sequence is a plane of width 1, the stride a multiplier on
+// the lane's patch position (3 is coprime with the 16 slots of a ds_read_b128 lane group: conflict-free).  Forward only in
+// practice: bias / output LeakyReLU epilogues; anything with an input activation, a derivative or a residual operand stays
+// on the f32 kernels.
+namespace {
+bool fill_c2x_from_1d(const ConvP& p, C2X* q) {
+    if (p.x6_mode != 1 || p.is == 1 || p.is == 2 || p.is == 4 || p.inner != 1 || p.nphase != 1 || p.os != 1) return false;
+    if (p.in_act != RH_ACT_NONE || p.epi_act != RH_ACT_NONE || p.mul_src || p.add || p.in_alpha || p.mul_alpha) return false;
+    if (p.in_row != p.in_valid || p.out_row != p.out_valid || p.ph_ntaps[0] < 1 || p.ph_ntaps[0] > kMaxTaps) return false;
+    *q = C2X{};
+    q->in = p.in; q->wq = p.wq; q->out = p.out; q->bias = p.bias;
+    q->B = p.B; q->C = p.C; q->M = p.M; q->Mp = p.Mp;
+    q->in_h = p.in_row; q->in_w = 1; q->out_h = p.out_row; q->out_w = 1;
+    q->rows = p.ncols; q->qcols = 1;
+    q->is_h = p.is; q->is_w = 1; q->os_h = 1; q->os_w = 1;
+    q->out_act = p.out_act; q->out_slope = p.out_slope;
+    q->nphase = 1;
+    q->ph_oph_h[0] = p.ph_oph[0]; q->ph_oph_w[0] = 0;
+    q->ph_ntaps[0] = p.ph_ntaps[0]; q->ph_tap0[0] = 0;
+    q->ph_minh[0] = p.ph_minoff[0]; q->ph_maxh[0] = p.ph_maxoff[0]; q->ph_minw[0] = q->ph_maxw[0] = 0;
+    q->ph_q2ofs[0] = p.ph_q2ofs[0];
+    for (int t = 0; t < p.ph_ntaps[0]; ++t) { q->offh[t] = p.off[p.ph_tap0[0] + t]; q->offw[t] = 0; }
+    q->wq_bytes = p.wq_bytes;
+    return true;
+}
+}  // namespace
+
+bool rh_conv_c2x_query(ConvP p) {
+    C2X q;
+    long v[8];
+    return x6_enabled() && fill_c2x_from_1d(p, &q) && rh_conv2d_x6_plan_query(q, v);
+}
+
+int rh_conv_launch_c2x(ConvP& p, hipStream_t stream, const char* what, bool* used) {
+    *used = false;
+    C2X q;
+    if (!x6_enabled() || !fill_c2x_from_1d(p, &q)) return RH_OK;
+    return rh_conv2d_x6_launch(q, stream, what, used);
 }

@@ -442,11 +442,13 @@ def test_conv2d_x6_tile_plans_cover_every_geometry():
                     base = kh * kw * cin * ((m + 31) // 32 * 32)
                     packed = L.lib.rh_conv2d_packed_floats(C.byref(d), which)
                     checked += 1
-                    if fam == 2:          # <= 4 output rows, stride 1, kh in (3, 9): vector-ALU kernels (conv2d_smallm.hip)
-                        assert m <= 4 and (sh, sw) == (1, 1) and dh == 1 and kh in (3, 9)
+                    valu_shape = (sh, sw) == (1, 1) and dh == 1 and kh in (3, 9)
+                    few_in = which == 0 and cin <= 4 and 4 < m <= 32        # first conv of a stack, forward (conv2d_smallc.hip)
+                    if fam == 2:          # <= 4 output rows (conv2d_smallm.hip) or <= 4 input channels: vector-ALU kernels
+                        assert valu_shape and (m <= 4 or few_in)
                         smallm += 1
                         continue
-                    assert not (m <= 4 and (sh, sw) == (1, 1) and dh == 1 and kh in (3, 9))
+                    assert not (valu_shape and (m <= 4 or few_in))
                     if cin % 16:
                         assert fam == 0 and packed == base
                         continue

@@ -153,6 +153,10 @@ CONV_CASES = [
     (3, 192, 96, 64, 3, 1, 3, (6, 0), 1, True, True),       # causal pad, batch folded, bias + residual
     (2, 96, 192, 1024, 1, 1, 1, (0, 0), 0, False, False),   # pointwise, no activation
     (9, 384, 768, 32, 3, 1, 1, (1, 1), 1, False, False),    # many channels on a short sequence: split-K over 16-channel chunks
+    # stride 3 (descript MPD, period-major rows): the forward takes the 2-D bf16x6 kernel with W = 1 (conv2d_x6.hip)
+    (3, 32, 128, 1093, 5, 3, 1, (2, 2), 0, True, False),    # 32 -> 128, bias, ragged length
+    (2, 128, 512, 365, 5, 3, 1, (2, 2), 0, True, False),    # 128 -> 512 (TM = 2, four chunks... eight row tiles)
+    (4, 48, 96, 40, 5, 3, 1, (2, 2), 0, False, False),      # short rows: batch folded into the column tile
 ]
 
 
