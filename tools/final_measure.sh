@@ -43,6 +43,14 @@ if has prof; then
   [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32_graph.md 2>&1
   rm -rf $O/profg
 fi
+if has prof2; then     # rocprofv3 kernel stats of the discrete (eager) and v3 (graph) GAN-phase steps
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_v3 -o p -- python $GRAFT_REPO_ROOT/bench.py --config v3 --phase gan --batch 16 --steps 8 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_v3.log 2>&1 < /dev/null)
+  f=$(find $O/prof_v3 -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_v3_gan_b16.md 2>&1; rm -rf $O/prof_v3
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_d -o p -- python $GRAFT_REPO_ROOT/bench.py --config discrete --phase gan --batch 32 --steps 8 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_discrete.log 2>&1 < /dev/null)
+  f=$(find $O/prof_d -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_discrete_gan_b32.md 2>&1; rm -rf $O/prof_d
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_g -o p -- python $GRAFT_REPO_ROOT/bench.py --phase gan --steps 8 --warmup 4 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/$O/prof_gan.log 2>&1 < /dev/null)
+  f=$(find $O/prof_g -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_gan_step.md 2>&1; rm -rf $O/prof_g
+fi
 if has pmc; then
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && RH_BWD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1 < /dev/null)
