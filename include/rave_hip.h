@@ -97,6 +97,20 @@ int rh_weight_norm_fwd_f32(const float* v, const float* g, int64_t rows, int64_t
 /* backward of the above: dv, dg from dw (torch _weight_norm_interface_backward). */
 int rh_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norms,
                            int64_t rows, int64_t cols, float* dv, float* dg, rh_stream_t stream);
+/* The same for MANY weight tensors in ONE launch (one workgroup per row over the concatenated rows; table by value in the
+ * kernel arguments, <= 64 tensors per launch): the weight-norm backward of every `normalization(conv)` of a backward pass
+ * (rave/blocks.py:15-22) collected and run once -- same arithmetic and bits as rh_weight_norm_bwd_f32 per tensor. */
+typedef struct rh_wn_bwd_item {
+    const float* dw;
+    const float* v;
+    const float* g;
+    const float* norms;
+    float* dv;
+    float* dg;
+    int64_t rows;
+    int64_t cols;
+} rh_wn_bwd_item;
+int rh_weight_norm_bwd_batched_f32(const rh_wn_bwd_item* items, int32_t n_items, rh_stream_t stream);
 
 /* Number of floats of the two packed (MFMA-friendly, K-major) copies of a weight tensor:
  * which = 0 -> operand of rh_conv1d_fwd_f32, which = 1 -> operand of rh_conv1d_bwd_data_f32. */
@@ -175,6 +189,18 @@ int64_t rh_conv1d_workspace_bytes(const rh_conv1d_desc* d);
 int rh_conv1d_bwd_weight_f32(const rh_conv1d_desc* d, const float* dy, const float* x,
                              const float* snake_alpha, float* dw, float* dbias, void* workspace,
                              int64_t workspace_bytes, rh_stream_t stream);
+/* The same weight gradient pushed through torch._weight_norm's backward (rave/blocks.py:15-22: `normalization` =
+ * weight_norm around every conv of the v2 / v3 generator; dim 0 = c_out for Conv1d, c_in for ConvTranspose1d):
+ *   dg[r] = <dw[r,:], v[r,:]> / ||v[r,:]||,   dv = (g/||v||) (dw - v <dw,v>/||v||^2)
+ * with `norms` = ||v[r,:]|| as the repack left them.  Where the K range was split, dv / dg come straight from the slice
+ * partials in ONE launch when RH_WN_FUSED=1 (the summed weight gradient is never written; bitwise the same result as
+ * rh_conv1d_bwd_weight_f32 + rh_weight_norm_bwd_f32 -- measured 3 % SLOWER on the v2 step, hence opt-in); otherwise dw
+ * goes through `dw_scratch` (weight-sized, contents undefined on return) and the plain weight-norm backward kernel. */
+int rh_conv1d_bwd_weight_wn_f32(const rh_conv1d_desc* d, const float* dy, const float* x, const float* snake_alpha,
+                                const float* v, const float* g, const float* norms, float* dw_scratch, float* dv,
+                                float* dg, float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream);
+/* Diagnostics: how many times this process took the one-launch form above (tests assert that it really runs). */
+int64_t rh_conv1d_bwd_weight_wn_fused_launches(void);
 
 /* ---- PQMF (rave/pqmf.py CachedPQMF, 16 bands) ------------------------------------------- */
 
@@ -385,6 +411,23 @@ int rh_kernel_events_used(void);
 int rh_event_create(void** event);                                   /* hipEventCreate (timing enabled) */
 int rh_event_destroy(void* event);
 int rh_event_elapsed_ms(void* start_event, void* stop_event, float* ms);   /* after the stream has been synchronised */
+
+/* ---- the generator loss of a training step (rave/model.py:336-344, 392-412) ---------------------------------------
+ * scaled[i] = w1_i * value_i  (the weighted distance the step logs: `self.weights[...] * v`, `reg * beta_factor`)
+ * total     = sum_i scaled[i] * w2_i, in term order from 0  (`loss_gen_value += v * self.weights.get(k, 1.)`)
+ * as one launch, and its gradient grads[i] = (grad_total * w2_i) * w1_i as another -- instead of ~2 scalar ATen launches per
+ * term in each direction between the forward and the backward pass.  Each product is rounded separately and the sum runs
+ * in order: the same bits as the ATen chain.  value / w1_dev: device scalars (w1_dev NULL -> the host value w1);
+ * <= 16 terms; the table travels by value (hipGraph-capturable). */
+typedef struct rh_loss_item {
+    const float* value;
+    const float* w1_dev;
+    float w1;
+    float w2;
+} rh_loss_item;
+int rh_loss_combine_fwd_f32(const rh_loss_item* items, int32_t n_items, float* scaled, float* total, rh_stream_t stream);
+int rh_loss_combine_bwd_f32(const rh_loss_item* items, int32_t n_items, const float* grad_total, float* grads,
+                            rh_stream_t stream);
 
 /* Adam step over many tensors (torch.optim.Adam, weight_decay = 0, amsgrad = False; rave/model.py:226-233): for every
  * item  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).

@@ -34,6 +34,17 @@ class AdamItem(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
+class WnBwdItem(C.Structure):
+    """Mirror of ``rh_wn_bwd_item`` (include/rave_hip.h)."""
+    _fields_ = [("dw", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("norms", C.c_void_p), ("dv", C.c_void_p),
+                ("dg", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64)]
+
+
+class LossItem(C.Structure):
+    """Mirror of ``rh_loss_item`` (include/rave_hip.h)."""
+    _fields_ = [("value", C.c_void_p), ("w1_dev", C.c_void_p), ("w1", C.c_float), ("w2", C.c_float)]
+
+
 class FmItem(C.Structure):
     """Mirror of ``rh_fm_item`` (include/rave_hip.h)."""
     _fields_ = [("f", C.c_void_p), ("df", C.c_void_p), ("half", C.c_int64), ("w", C.c_float)]
@@ -60,6 +71,7 @@ def _load() -> C.CDLL:
         "rh_last_error": ([], C.c_char_p),
         "rh_weight_norm_fwd_f32": ([P, P, I64, I64, P, P, P], C.c_int),
         "rh_weight_norm_bwd_f32": ([P, P, P, P, I64, I64, P, P, P], C.c_int),
+        "rh_weight_norm_bwd_batched_f32": ([C.POINTER(WnBwdItem), I32, P], C.c_int),
         "rh_conv1d_packed_floats": ([D, C.c_int], I64),
         "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
         "rh_conv1d_pack_wn_f32": ([D, P, P, P, P, P, P, P], C.c_int),
@@ -78,6 +90,8 @@ def _load() -> C.CDLL:
         "rh_conv1d_bwd_data_workspace_bytes": ([D], I64),
         "rh_conv1d_workspace_bytes": ([D], I64),
         "rh_conv1d_bwd_weight_f32": ([D, P, P, P, P, P, P, I64, P], C.c_int),
+        "rh_conv1d_bwd_weight_wn_f32": ([D, P, P, P, P, P, P, P, P, P, P, P, I64, P], C.c_int),
+        "rh_conv1d_bwd_weight_wn_fused_launches": ([], I64),
         "rh_conv2d_packed_floats": ([D2, C.c_int], I64),
         "rh_conv2d_pack_f32": ([D2, P, P, P, P], C.c_int),
         "rh_conv2d_fwd_f32": ([D2, P, P, P, P, P], C.c_int),
@@ -114,6 +128,8 @@ def _load() -> C.CDLL:
         "rh_reparam_workspace_bytes": ([], I64),
         "rh_reparam_fwd_f32": ([P, P, I32, I32, I32, P, P, P, I64, P], C.c_int),
         "rh_reparam_bwd_f32": ([P, P, P, P, I32, I32, I32, P, P], C.c_int),
+        "rh_loss_combine_fwd_f32": ([C.POINTER(LossItem), I32, P, P, P], C.c_int),
+        "rh_loss_combine_bwd_f32": ([C.POINTER(LossItem), I32, P, P, P], C.c_int),
         "rh_adam_step_f32": ([C.POINTER(AdamItem), I32, P, F, F, F, P, P, P], C.c_int),
         "rh_set_kernel_events": ([P, P], C.c_int),
         "rh_kernel_events_used": ([], C.c_int),

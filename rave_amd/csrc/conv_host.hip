@@ -2,8 +2,6 @@
 // packing, and the extern "C" functions declared in include/rave_hip.h.
 #include "conv_params.hpp"
 
-int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const float* alpha,
-                 float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t stream);
 int64_t rh_wgrad_workspace(const rh_conv1d_desc* d);
 
 namespace {
@@ -715,4 +713,15 @@ extern "C" int rh_conv1d_bwd_weight_f32(const rh_conv1d_desc* d, const float* dy
     RH_REQUIRE(dw && (d->batch == 0 || (dy && x)), RH_ERR_INVALID, "conv1d_bwd_weight: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_weight: snake needs alpha");
     return rh_wgrad_run(d, dy, x, snake_alpha, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int rh_conv1d_bwd_weight_wn_f32(const rh_conv1d_desc* d, const float* dy, const float* x, const float* snake_alpha,
+                                           const float* v, const float* g, const float* norms, float* dw_scratch, float* dv,
+                                           float* dg, float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    if (int e = validate(d)) return e;
+    RH_REQUIRE(dw_scratch && v && g && norms && dv && dg && (d->batch == 0 || (dy && x)), RH_ERR_INVALID,
+               "conv1d_bwd_weight_wn: null pointer");
+    RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_bwd_weight_wn: snake needs alpha");
+    const RhWnTail tail{v, g, norms, dv, dg};
+    return rh_wgrad_run(d, dy, x, snake_alpha, dw_scratch, dbias, workspace, workspace_bytes, (hipStream_t)stream, &tail);
 }

@@ -126,6 +126,16 @@ int64_t rh_bias_grad_workspace(int M);
 int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db, int B, int M, long plane, int act,
                         float slope, hipStream_t stream, float* g_out = nullptr);
 int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what);
+// weight norm behind a weight gradient: the caller wants dv, dg of w = g v/||v|| (dim 0) instead of dw
+struct RhWnTail {
+    const float* v;
+    const float* g;
+    const float* norms;
+    float* dv;
+    float* dg;
+};
+int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const float* alpha, float* dw, float* dbias, void* ws,
+                 int64_t ws_bytes, hipStream_t stream, const RhWnTail* tail = nullptr);
 
 int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p);
 int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p);

@@ -6,6 +6,7 @@
 // The activation of the forward input is re-applied on the fly (the reference keeps a separate
 // activated tensor alive for autograd).  Split-K over (batch, position chunks) with partials in
 // caller-provided scratch and an ordered second pass -> bitwise deterministic.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include "conv_params.hpp"
@@ -167,6 +168,86 @@ static void reduce_partials_go(const float* part, float* out, long n, int Z, hip
     } else {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)rh_cdiv64(n, 64)), dim3(256), 0, stream, part, out, n, Z);
     }
+}
+
+// reduce_partials + weight_norm_bwd_kernel (misc.hip) as ONE launch per layer: a workgroup owns a complete dim-0 row of the
+// weight tensor -- exactly the unit torch._weight_norm's backward (rave/blocks.py:15-22: weight_norm on every conv of the
+// generator) needs: it sums the row's K-slice partials in the SAME fixed order as the two kernels above (order4 = the vec4
+// kernel's: four running sums over z % 4; otherwise four waves on z = w, w + 4, ... with eight running sums each), keeps
+// the summed row in LDS, forms <dw, v> in weight_norm_bwd_kernel's order (256 partial sums, shuffle tree, four waves) and
+// writes dv = (g/||v||)(dw - v <dw,v>/||v||^2), dg = <dw,v>/||v||.  dw itself never exists in memory; bitwise the same
+// dv / dg as the two-launch path.  16 waves: 4 z groups x 4 column groups of 64 lanes x 4 consecutive elements (a pass
+// covers 1024 row elements; 96-row layers with 256 K slices keep 8 x 16 B x 64 lanes in flight per active wave).
+constexpr int kRwnMaxN = 8192;
+__global__ __launch_bounds__(1024) void reduce_wn_bwd_kernel(const float* __restrict__ part, long zstride, int Z, int N, int order4,
+                                                             const float* __restrict__ v, const float* __restrict__ g,
+                                                             const float* __restrict__ norms, float* __restrict__ dv,
+                                                             float* __restrict__ dg) {
+    extern __shared__ __attribute__((aligned(16))) float rwn_sm[];
+    f32x4* const red = reinterpret_cast<f32x4*>(rwn_sm);            // [z group][column group][lane]
+    float* const dwrow = rwn_sm + 4096;                             // [N]
+    f32x4* const dwrow4 = reinterpret_cast<f32x4*>(dwrow);
+    __shared__ float wred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long r = blockIdx.x;
+    const int N4 = N >> 2;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(part + r * N);
+    const long zs4 = zstride >> 2;
+    if (order4) {
+        for (int e4 = tid; e4 < N4; e4 += 1024) {
+            f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            int z = 0;
+            for (; z + 3 < Z; z += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 t = src[(long)(z + u) * zs4 + e4];
+                    s[u] += t;
+                }
+            }
+            for (; z < Z; ++z) s[0] += src[(long)z * zs4 + e4];
+            dwrow4[e4] = (s[0] + s[1]) + (s[2] + s[3]);
+        }
+    } else {
+        const int cg = wave & 3, zg = wave >> 2;
+        for (int c0 = 0; c0 < N4; c0 += 256) {
+            const int e4 = c0 + cg * 64 + lane;
+            f32x4 s[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e4 < N4) {
+                int z = zg;
+                for (; z + 28 < Z; z += 32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const f32x4 t = src[(long)(z + 4 * u) * zs4 + e4];
+                        s[u] += t;
+                    }
+                }
+                for (; z < Z; z += 4) s[0] += src[(long)z * zs4 + e4];
+            }
+            red[(zg * 4 + cg) * 64 + lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            __syncthreads();
+            if (zg == 0 && e4 < N4)
+                dwrow4[e4] = (red[cg * 64 + lane] + red[(4 + cg) * 64 + lane]) + (red[(8 + cg) * 64 + lane] + red[(12 + cg) * 64 + lane]);
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const float* __restrict__ vr = v + r * N;
+    float s = 0.f;
+    if (tid < 256)
+        for (int e = tid; e < N; e += 256) s += dwrow[e] * vr[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (tid < 256 && lane == 0) wred[wave] = s;
+    __syncthreads();
+    const float dot = wred[0] + wred[1] + wred[2] + wred[3];
+    const float norm = norms[r];
+    const float scale = g[r] / norm;
+    const float coef = dot / (norm * norm);
+    float* __restrict__ dvr = dv + r * N;
+    for (int e = tid; e < N; e += 1024) dvr[e] = scale * (dwrow[e] - vr[e] * coef);
+    if (tid == 0) dg[r] = dot / norm;
 }
 
 // dbias[m] = sum_{b,h,w} dy * act'(y): grid (M, kBiasSlices) partial sums over interleaved 1024-element segments
@@ -611,7 +692,9 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
 }  // namespace
 
 int64_t rh_wgrad_x6_workspace(const WgradP& w);
-int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used);
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used, int* left_z);
+int rh_reduce_wn_bwd_launch(const float* part, int Z, long M, long N, const float* v, const float* g, const float* norms,
+                            float* dv, float* dg, hipStream_t stream, bool* used);
 
 extern "C" int rh_conv1d_bwd_weight_kernel_family(const rh_conv1d_desc* d) {
     if (!d || d->batch <= 0) return 0;
@@ -637,10 +720,19 @@ int64_t rh_wgrad_workspace(const rh_conv1d_desc* d) {
     return bias + (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float);
 }
 
+extern "C" int rh_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norms, int64_t rows,
+                                      int64_t cols, float* dv, float* dg, rh_stream_t stream);
+
+// tail != null: the weight is weight-normed (w = g v/||v||, dim 0 = the rows of dw in both conv directions) and the caller
+// wants dv, dg instead of dw: straight from the K-slice partials where the row fits (reduce_wn_bwd_kernel), else through dw.
 int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const float* alpha,
-                 float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                 float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t stream, const RhWnTail* tail) {
     WgradP p{};
     fill(d, &p);
+    auto through_dw = [&](int e) {
+        if (e || !tail) return e;
+        return rh_weight_norm_bwd_f32(dw, tail->v, tail->g, tail->norms, p.M, (int64_t)p.C * p.T, tail->dv, tail->dg, (rh_stream_t)stream);
+    };
     if (!d->transposed) { p.R = dy; p.S = x; p.r_alpha = nullptr; p.s_alpha = alpha; }
     else                { p.R = x; p.S = dy; p.r_alpha = alpha; p.s_alpha = nullptr; }
     const long nw = (long)p.M * p.C * p.T;
@@ -649,7 +741,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
         const int64_t need = rh_smallc_wgrad_workspace(d);
         RH_REQUIRE(ws && ws_bytes >= need, RH_ERR_WORKSPACE, "conv1d_bwd_weight: workspace %lld B < %lld B",
                    (long long)ws_bytes, (long long)need);
-        return rh_smallc_wgrad(d, dy, x, dw, dbias, ws, stream);
+        return through_dw(rh_smallc_wgrad(d, dy, x, dw, dbias, ws, stream));
     }
     // Conv1d on the bf16x6 weight-gradient kernel: the bias gradient (row sums of dy) comes out of the same pass
     const bool x6_path = d->act != RH_ACT_SNAKE && p.B > 0 && p.r_row > 0 && rh_wgrad_x6_workspace(p) >= 0;
@@ -667,7 +759,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     if (p.B <= 0 || p.r_row <= 0) {
         (void)hipMemsetAsync(dw, 0, nw * sizeof(float), stream);
         if (dbias) (void)hipMemsetAsync(dbias, 0, d->c_out * sizeof(float), stream);
-        return RH_OK;
+        return through_dw(RH_OK);
     }
     if (d->act != RH_ACT_SNAKE) {
         const int64_t x6 = rh_wgrad_x6_workspace(p);
@@ -675,8 +767,17 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
             RH_REQUIRE(x6 == 0 || (ws && ws_bytes >= x6), RH_ERR_WORKSPACE,
                        "conv1d_bwd_weight: workspace %lld B < %lld B", (long long)ws_bytes, (long long)x6);
             bool used = false;
-            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used)) return e;
-            if (used) return RH_OK;
+            int left_z = 0;      // > 0: the partials were left unreduced in ws for the fused tail
+            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used, tail ? &left_z : nullptr)) return e;
+            if (used && left_z > 1) {
+                bool fused = false;
+                if (int e = rh_reduce_wn_bwd_launch((const float*)ws, left_z, p.M, (long)p.C * p.T, tail->v, tail->g, tail->norms,
+                                                    tail->dv, tail->dg, stream, &fused))
+                    return e;
+                if (fused) return RH_OK;
+                return through_dw(rh_reduce_partials_launch((const float*)ws, dw, nw, left_z, stream, "conv1d_bwd_weight_reduce"));
+            }
+            if (used) return through_dw(RH_OK);
         }
     }
     const WPlan w = plan(p);
@@ -692,10 +793,17 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
     else e = launch_w<2, 2, 2, 2>(p, w, stream);
     if (e) return e;
     if (w.Z > 1) {
+        if (tail) {
+            bool fused = false;
+            if (int e2 = rh_reduce_wn_bwd_launch((const float*)ws, w.Z, p.M, nw / p.M, tail->v, tail->g, tail->norms, tail->dv,
+                                                 tail->dg, stream, &fused))
+                return e2;
+            if (fused) return RH_OK;
+        }
         reduce_partials_go((const float*)ws, dw, nw, w.Z, stream);
-        return rh_check_launch("conv1d_bwd_weight_reduce");
+        return through_dw(rh_check_launch("conv1d_bwd_weight_reduce"));
     }
-    return RH_OK;
+    return through_dw(RH_OK);
 }
 
 int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what) {
@@ -703,6 +811,32 @@ int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipS
     reduce_partials_go(part, out, n, Z, stream);
     return rh_check_launch(what);
 }
+
+// K-slice partials [Z][M][N] -> dv, dg of the weight-normed parameter in one launch (reduce_wn_bwd_kernel).  *used = false
+// (nothing launched) when the row does not fit: the caller reduces into dw and runs weight_norm_bwd.
+static std::atomic<int64_t> g_rwn_launches{0};       // diagnostics: how often the one-launch form ran (tests)
+int rh_reduce_wn_bwd_launch(const float* part, int Z, long M, long N, const float* v, const float* g, const float* norms,
+                            float* dv, float* dg, hipStream_t stream, bool* used) {
+    *used = false;
+    // OPT-IN (RH_WN_FUSED=1; read per call: tests).  Measured on the v2 step (batch 32, graph replay, same box, two runs
+    // each): 10.29 / 10.27 ms with this launch against 9.99 / 10.02 ms with reduce_partials + weight_norm_bwd -- one
+    // workgroup per row means 96 ... 768 workgroups pull the 2.5 GB of partials of a step where reduce_partials_kernel
+    // spreads them over 4 x as many, and a 16-wave workgroup waits for a whole free CU beside the conv kernels of the other
+    // stream (profiles/round4_negative_fused_reduce_weight_norm.txt).  Kept for the bit-identity test and as evidence.
+    const char* e = getenv("RH_WN_FUSED");
+    if (!(e && atoi(e) == 1)) return RH_OK;
+    if (Z < 2 || M <= 0 || N <= 0 || (N & 3) || N > kRwnMaxN || ((uintptr_t)part & 15)) return RH_OK;
+    const long n = M * N;
+    // (the order reduce_partials_go would have taken for this tensor; its dw scratch is always 16-byte aligned)
+    const int order4 = Z <= 16 && n >= (1l << 16);
+    hipLaunchKernelGGL(reduce_wn_bwd_kernel, dim3((unsigned)M), dim3(1024), (size_t)(4096 + N) * sizeof(float), stream, part, n, Z,
+                       (int)N, order4, v, g, norms, dv, dg);
+    *used = true;
+    ++g_rwn_launches;
+    return rh_check_launch("conv1d_bwd_weight_reduce_wn");
+}
+
+extern "C" int64_t rh_conv1d_bwd_weight_wn_fused_launches(void) { return g_rwn_launches.load(); }
 
 int64_t rh_bias_grad_workspace(int M) { return (int64_t)M * kBiasSlices * (int64_t)sizeof(float); }
 

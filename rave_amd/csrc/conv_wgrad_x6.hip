@@ -362,8 +362,11 @@ int64_t rh_wgrad_x6_workspace(const WgradP& w) {
 
 // Returns RH_OK with *used = false when the geometry does not fit this path.  ws must hold rh_wgrad_x6_workspace bytes.
 // rsum_out != null: also the row sums of R over (batch, position) -- the bias gradient when R = dy -- from the same pass
-int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used) {
+// left_z != null and the K range was split: the weight partials stay UNREDUCED in ws ([Z][M][C*T], *left_z = Z) for a caller
+// that folds the reduction into its next pass (conv_wgrad.hip: reduce_wn_bwd_kernel); the bias partials are reduced here.
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used, int* left_z) {
     *used = false;
+    if (left_z) *left_z = 0;
     Wx6P p;
     Wx6Plan pl{};
     if (!plan_wx6(w, &p, &pl)) return RH_OK;
@@ -382,7 +385,8 @@ int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hi
     if (int e = rh_check_launch("conv1d_bwd_weight_x6")) return e;
     *used = true;
     if (pl.Z > 1) {
-        if (int e = rh_reduce_partials_launch((const float*)ws, dw, (long)w.M * w.C * w.T, pl.Z, stream, "conv1d_bwd_weight_reduce")) return e;
+        if (left_z) *left_z = pl.Z;
+        else if (int e = rh_reduce_partials_launch((const float*)ws, dw, (long)w.M * w.C * w.T, pl.Z, stream, "conv1d_bwd_weight_reduce")) return e;
         if (rsum_out) return rh_reduce_partials_launch(rs_part, rsum_out, w.M, pl.Z, stream, "conv1d_bwd_bias_reduce");
     }
     return RH_OK;

@@ -42,11 +42,9 @@ __global__ __launch_bounds__(256) void weight_norm_scales_kernel(const float* __
 }
 
 // dg[r] = <dw, v> / ||v|| ;  dv = (g/||v||) * (dw - v * <dw, v> / ||v||^2)
-__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
-                                                              const float* __restrict__ g, const float* __restrict__ norms,
-                                                              long cols, float* __restrict__ dv, float* __restrict__ dg) {
-    __shared__ float red[4];
-    const long r = blockIdx.x;
+__device__ __forceinline__ void weight_norm_bwd_row(const float* __restrict__ dw, const float* __restrict__ v,
+                                                    const float* __restrict__ g, const float* __restrict__ norms, long r,
+                                                    long cols, float* __restrict__ dv, float* __restrict__ dg, float* red) {
     const float* vr = v + r * cols;
     const float* dwr = dw + r * cols;
     float s = 0.f;
@@ -58,6 +56,42 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
     float* dvr = dv + r * cols;
     for (long e = threadIdx.x; e < cols; e += 256) dvr[e] = scale * (dwr[e] - vr[e] * coef);
     if (threadIdx.x == 0) dg[r] = dot / norm;
+}
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                              const float* __restrict__ g, const float* __restrict__ norms,
+                                                              long cols, float* __restrict__ dv, float* __restrict__ dg) {
+    __shared__ float red[4];
+    weight_norm_bwd_row(dw, v, g, norms, blockIdx.x, cols, dv, dg, red);
+}
+
+// The same row program for MANY weight tensors in one launch: the backward pass of a v2 step runs 56 of these 4-6 us
+// latency-bound launches (one per weight-normed conv, 0.35 ms) whose only consumer is the optimizer; collected and run
+// once per backward pass / gradient bucket they are one bandwidth-bound pass over the weights (rave_amd/ops.py:
+// _WN_PENDING).  The table travels by value in the kernel arguments (as adam.hip's): recorded with the launch by a hipGraph
+// capture.  One workgroup per row, rows of all tensors concatenated; same arithmetic, same bits as the kernel above.
+constexpr int kWnItems = 64;
+struct WnTable {
+    const float* dw[kWnItems];
+    const float* v[kWnItems];
+    const float* g[kWnItems];
+    const float* norms[kWnItems];
+    float* dv[kWnItems];
+    float* dg[kWnItems];
+    int row_begin[kWnItems + 1];
+    int cols[kWnItems];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_batched_kernel(const WnTable tb) {
+    __shared__ float red[4];
+    int lo = 0, hi = tb.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tb.row_begin[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    weight_norm_bwd_row(tb.dw[lo], tb.v[lo], tb.g[lo], tb.norms[lo], (long)((int)blockIdx.x - tb.row_begin[lo]), (long)tb.cols[lo],
+                        tb.dv[lo], tb.dg[lo], red);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -259,6 +293,36 @@ extern "C" int rh_weight_norm_bwd_f32(const float* dw, const float* v, const flo
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dw, v, g,
                        norms, (long)cols, dv, dg);
     return rh_check_launch("weight_norm_bwd");
+}
+
+extern "C" int rh_weight_norm_bwd_batched_f32(const rh_wn_bwd_item* items, int32_t n_items, rh_stream_t stream) {
+    RH_REQUIRE(n_items >= 0 && (n_items == 0 || items), RH_ERR_INVALID, "weight_norm_bwd_batched: bad arguments");
+    for (int i = 0; i < n_items;) {
+        WnTable tb;
+        int cnt = 0;
+        long rows = 0;
+        for (; i < n_items && cnt < kWnItems; ++i) {
+            const rh_wn_bwd_item& it = items[i];
+            RH_REQUIRE(it.dw && it.v && it.g && it.norms && it.dv && it.dg && it.rows >= 0 && it.cols > 0 && it.cols < 0x7fffffffl,
+                       RH_ERR_INVALID, "weight_norm_bwd_batched: bad item %d", i);
+            if (it.rows == 0) continue;
+            if (rows + it.rows >= 0x7fffffffl) break;          // (next launch)
+            tb.dw[cnt] = it.dw; tb.v[cnt] = it.v; tb.g[cnt] = it.g; tb.norms[cnt] = it.norms; tb.dv[cnt] = it.dv; tb.dg[cnt] = it.dg;
+            tb.cols[cnt] = (int)it.cols;
+            tb.row_begin[cnt] = (int)rows;
+            rows += it.rows;
+            ++cnt;
+        }
+        if (cnt == 0) {
+            RH_REQUIRE(i >= n_items || items[i].rows < 0x7fffffffl, RH_ERR_UNSUPPORTED, "weight_norm_bwd_batched: too many rows");
+            continue;
+        }
+        tb.row_begin[cnt] = (int)rows;
+        tb.count = cnt;
+        hipLaunchKernelGGL(weight_norm_bwd_batched_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, tb);
+        if (int e = rh_check_launch("weight_norm_bwd_batched")) return e;
+    }
+    return RH_OK;
 }
 
 extern "C" int rh_amp_tanh_fwd_f32(const float* x, int32_t batch, int32_t c, int32_t l, float* y,
@@ -509,6 +573,70 @@ __global__ void spectral_total_kernel(const float* __restrict__ sums, const floa
         for (int s = 0; s < S; ++s) d += sums[3 * s] / sums[3 * s + 1] + sums[3 * s + 2] * inv_n[s];
         out[0] = d;
     }
+}
+
+// ---- the generator loss: scaled_i = w1_i * value_i (what the step logs), total = sum_i scaled_i * w2_i, as ONE one-thread
+// launch instead of ~2 scalar ATen launches per term forward and backward (rave/model.py:336-344,392-412: `weights[...] * v`
+// per distance, then `loss_gen_value += v * self.weights.get(k, 1.)`).  Every product is rounded on its own and the sum
+// runs in term order from 0.0f -- bit for bit what the ATen chain computes (no contraction into FMAs).
+constexpr int kLossItems = 16;
+struct LossTable {
+    const float* value[kLossItems];
+    const float* w1_dev[kLossItems];      // device scalar (beta_factor of a recorded step) or null -> w1
+    float w1[kLossItems];
+    float w2[kLossItems];
+    int count;
+};
+
+__global__ void loss_combine_fwd_kernel(const LossTable tb, float* __restrict__ scaled, float* __restrict__ total) {
+#pragma clang fp contract(off)          // (plain * and + below: hip's __fmul_rn / __fadd_rn are inlined with contraction allowed)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t = 0.f;
+    for (int i = 0; i < tb.count; ++i) {
+        const float w = tb.w1_dev[i] ? tb.w1_dev[i][0] : tb.w1[i];
+        const float sc = tb.value[i][0] * w;
+        scaled[i] = sc;
+        const float term = sc * tb.w2[i];
+        t = t + term;
+    }
+    total[0] = t;
+}
+
+// d total / d value_i = (g * w2_i) * w1_i  (the order autograd's two MulBackward nodes multiply in)
+__global__ void loss_combine_bwd_kernel(const LossTable tb, const float* __restrict__ g, float* __restrict__ grads) {
+#pragma clang fp contract(off)
+    const int i = threadIdx.x;
+    if (blockIdx.x != 0 || i >= tb.count) return;
+    const float w = tb.w1_dev[i] ? tb.w1_dev[i][0] : tb.w1[i];
+    const float gw = g[0] * tb.w2[i];
+    grads[i] = gw * w;
+}
+
+static int loss_table(const rh_loss_item* items, int32_t n, LossTable* tb, const char* what) {
+    RH_REQUIRE(items && n > 0 && n <= kLossItems, RH_ERR_INVALID, "%s: 1 .. %d terms", what, kLossItems);
+    for (int i = 0; i < n; ++i) {
+        RH_REQUIRE(items[i].value, RH_ERR_INVALID, "%s: null value %d", what, i);
+        tb->value[i] = items[i].value; tb->w1_dev[i] = items[i].w1_dev; tb->w1[i] = items[i].w1; tb->w2[i] = items[i].w2;
+    }
+    tb->count = n;
+    return RH_OK;
+}
+
+extern "C" int rh_loss_combine_fwd_f32(const rh_loss_item* items, int32_t n_items, float* scaled, float* total, rh_stream_t stream) {
+    LossTable tb;
+    if (int e = loss_table(items, n_items, &tb, "loss_combine_fwd")) return e;
+    RH_REQUIRE(scaled && total, RH_ERR_INVALID, "loss_combine_fwd: null output");
+    hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tb, scaled, total);
+    return rh_check_launch("loss_combine_fwd");
+}
+
+extern "C" int rh_loss_combine_bwd_f32(const rh_loss_item* items, int32_t n_items, const float* grad_total, float* grads,
+                                       rh_stream_t stream) {
+    LossTable tb;
+    if (int e = loss_table(items, n_items, &tb, "loss_combine_bwd")) return e;
+    RH_REQUIRE(grad_total && grads, RH_ERR_INVALID, "loss_combine_bwd: null pointer");
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tb, grad_total, grads);
+    return rh_check_launch("loss_combine_bwd");
 }
 
 extern "C" int rh_spectral_total_f32(const float* sums, const float* inv_n, int32_t n_scales, float* out, rh_stream_t stream) {

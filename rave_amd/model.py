@@ -24,6 +24,12 @@ _default_loss_weights = {
 }
 
 
+def _loss_combine_fused() -> bool:
+    """RH_LOSS_COMBINE=0: the generator loss as the reference's chain of scalar ATen operations (same bits)."""
+    import os
+    return os.environ.get("RH_LOSS_COMBINE", "1") != "0"
+
+
 def _pqmf_encode(pq, x: torch.Tensor):
     """rave/model.py:116-122."""
     batch_size = x.shape[:-2]
@@ -267,13 +273,15 @@ class RAVE(nn.Module):
             y_multiband = valid_signal_crop(y_multiband, rf[0], rf[1])
         x_multiband = x_mb_loss
 
-        distances = {}
+        # the generator loss terms as (value, first factor): on the GPU the products and the weighted sum of
+        # rave/model.py:336-344, 392-412 are ONE launch each way (ops.loss_combine, same bits as the ATen chain below)
+        terms = {}
         multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
         for k, v in multiband_distance.items():
-            distances[f"multiband_{k}"] = self.weights["multiband_audio_distance"] * v
+            terms[f"multiband_{k}"] = (v, self.weights["multiband_audio_distance"])
         fullband_distance = self.audio_distance(x_raw, y_raw)
         for k, v in fullband_distance.items():
-            distances[f"fullband_{k}"] = self.weights["audio_distance"] * v
+            terms[f"fullband_{k}"] = (v, self.weights["audio_distance"])
 
         feature_matching_distance = 0.
         dis_step = bool(self.warmed_up) and not (batch_idx % self.update_discriminator_every)
@@ -310,18 +318,32 @@ class RAVE(nn.Module):
             loss_dis = torch.zeros((), device=x_raw.device, dtype=x_raw.dtype)     # (no host-to-device copy)
             loss_adv = torch.zeros((), device=x_raw.device, dtype=x_raw.dtype)
 
-        loss_gen = {}
-        loss_gen.update(distances)
         if capture_safe:
             # per-step host scalars must not be baked into a recorded graph: beta_factor is changed every step by the
             # reference's BetaWarmupCallback (rave/model.py:83-107), so the captured step reads it from a 0-d device
             # tensor that GraphedTrainingStep refreshes (fill_) before every replay -- same f32 product as `reg * float`
-            loss_gen["regularization"] = reg * self.beta_device(reg.device)
+            terms["regularization"] = (reg, self.beta_device(reg.device))
         elif reg.item():
-            loss_gen["regularization"] = reg * self.beta_factor
+            terms["regularization"] = (reg, self.beta_factor)
         if self.warmed_up:
-            loss_gen["feature_matching"] = self.weights["feature_matching"] * feature_matching_distance
-            loss_gen["adversarial"] = self.weights["adversarial"] * loss_adv
+            terms["feature_matching"] = (feature_matching_distance, self.weights["feature_matching"])
+            terms["adversarial"] = (loss_adv, self.weights["adversarial"])
+        fused_sum = _loss_combine_fused() and all(torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32
+                                                  and v.numel() == 1 for v, _ in terms.values()) and 0 < len(terms) <= 16
+        loss_gen = {}
+        loss_gen_value = None
+        if fused_sum:
+            from . import ops
+            names = list(terms)
+            w1 = [0. if torch.is_tensor(terms[k][1]) else terms[k][1] for k in names]
+            w1_dev = [terms[k][1] if torch.is_tensor(terms[k][1]) else None for k in names]
+            loss_gen_value, scaled = ops.loss_combine([terms[k][0] for k in names], w1, [self.weights.get(k, 1.) for k in names],
+                                                      w1_dev)
+            for i, k in enumerate(names):
+                loss_gen[k] = scaled[i]
+        else:
+            for k, (v, w) in terms.items():
+                loss_gen[k] = (v * w) if torch.is_tensor(w) else (w * v)
 
         if dis_step:
             dis_opt.zero_grad()
@@ -335,9 +357,10 @@ class RAVE(nn.Module):
             gen_opt.zero_grad()
             if grad_begin is not None:
                 grad_begin(0)
-            loss_gen_value = 0.
-            for k, v in loss_gen.items():
-                loss_gen_value += v * self.weights.get(k, 1.)
+            if loss_gen_value is None:
+                loss_gen_value = 0.
+                for k, v in loss_gen.items():
+                    loss_gen_value += v * self.weights.get(k, 1.)
             loss_gen_value.backward()
             if grad_sync is not None:
                 grad_sync(0)

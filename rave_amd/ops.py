@@ -326,11 +326,38 @@ def _side_stream(device):
     return st
 
 
+# Weight-norm backward of the layers whose weight gradient ran on the side stream: collected here and run as ONE launch
+# (rh_weight_norm_bwd_batched_f32) when the branch is joined -- at the end of the backward pass or when a data-parallel
+# bucket leaves -- instead of one 4-6 us latency-bound launch per layer (56 per v2 step).  The dv / dg tensors handed to
+# autograd are filled by that launch: like every gradient of the side stream they are valid once the branch is joined.
+# RH_WN_BATCH=0: one launch per layer, at once.
+_WN_PENDING = []
+
+
+def _wn_batch_enabled() -> bool:
+    import os
+    return os.environ.get("RH_WN_BATCH", "1") != "0"
+
+
+def _flush_wn_pending(stream_ptr) -> None:
+    items, _WN_PENDING[:] = list(_WN_PENDING), []
+    arr = (L.WnBwdItem * len(items))()
+    for a, (dw, v, g, norms, dv, dg) in zip(arr, items):
+        a.dw, a.v, a.g, a.norms, a.dv, a.dg = L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(norms), L.ptr(dv), L.ptr(dg)
+        a.rows = v.shape[0]
+        a.cols = v.numel() // max(v.shape[0], 1)
+    L.check(L.lib.rh_weight_norm_bwd_batched_f32(arr, len(items), stream_ptr), "weight_norm_bwd_batched")
+
+
 def join_side_streams() -> None:
-    """The calling stream waits for everything enqueued on the weight-gradient side stream."""
+    """The calling stream waits for everything enqueued on the weight-gradient side stream (after the collected
+    weight-norm backward launches of that branch have been enqueued there)."""
     pend = _SIDE_PENDING[0]
     if pend is not None:
         main, side = pend
+        if _WN_PENDING:
+            with torch.cuda.stream(side):
+                _flush_wn_pending(L.stream())
         main.wait_stream(side)
         torch.cuda.current_stream().wait_stream(side)
         _SIDE_PENDING[0] = None
@@ -498,6 +525,28 @@ def _wn_bwd(dw, v, g, norms, s, slot_v=None, slot_g=None):
     return dv, dg
 
 
+def _wgrad_wn(d, dy, x, alpha, dw, db, v, g, norms, ws, nbytes, s, slot_v=None, slot_g=None, side=None):
+    """Weight gradient of a weight-normed conv: (dv, dg).  On the side stream (``side.active``) only the weight gradient is
+    launched here; weight norm's backward joins the batch that runs when the branch is joined (_WN_PENDING).  Otherwise ONE C
+    call (rh_conv1d_bwd_weight_wn_f32: weight gradient, ordered reduction, weight-norm backward).  The instrumented modes
+    (per-launch profile, exact-f32 shadow run) keep the two separate calls they account for."""
+    if _PROFILE is not None or _SHADOW is not None:
+        L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
+        return _wn_bwd(dw, v, g, norms, s, slot_v, slot_g)
+    dv = _grad_out(slot_v, v.shape, v.device)
+    dg = _grad_out(slot_g, g.shape, g.device)
+    if side is not None and side.active and _wn_batch_enabled():
+        L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
+        # (aliases of dv / dg keep the storage alive until the batch has run; the tensor OBJECTS handed to autograd must have
+        # no other holder, or AccumulateGrad clones -- i.e. reads -- them instead of adopting them)
+        _WN_PENDING.append((dw, v, g, norms, dv.detach(), dg.detach()))
+        return dv, dg
+    L.check(L.lib.rh_conv1d_bwd_weight_wn_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(v), L.ptr(g), L.ptr(norms),
+                                              L.ptr(dw), L.ptr(dv), L.ptr(dg), L.ptr(db), L.ptr(ws), nbytes, s),
+            "conv1d_bwd_weight_wn")
+    return dv, dg
+
+
 class _ConvFn(torch.autograd.Function):
     """y = conv(act(x), w) + bias + residual, w = weight (g is None) or g*weight/||weight|| (weight norm
     folded in).  rh_conv1d_fwd_f32 and its gradients."""
@@ -558,10 +607,11 @@ class _ConvFn(torch.autograd.Function):
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
             with _OnSide(dy.device, dy, x, ws, dw, db, v, g, norms, alpha, allow=side_ok) as side:
                 s2 = L.stream()
-                L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s2), "conv1d_bwd_weight")
-                if g is not None:
+                if g is None:
+                    L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s2), "conv1d_bwd_weight")
+                else:
                     dw_full = dw
-                    dw, dg = _wn_bwd(dw, v, g, norms, s2, slot_w, slot_g)
+                    dw, dg = _wgrad_wn(d, dy, x, alpha, dw, db, v, g, norms, ws, nbytes, s2, slot_w, slot_g, side)
                     side.keep(dw_full, dw, dg)
         if alpha is not None and ctx.needs_input_grad[4]:
             raise NotImplementedError("rave_amd: gradient w.r.t. a fused Snake alpha; use rave_amd.blocks.Snake + conv")
@@ -671,17 +721,19 @@ class _ResidualUnitFn(torch.autograd.Function):
                 s3w, s3g, s1w, s1g = ctx.slots
                 dw1 = _grad_out(s1w if g1w is None else None, ctx.w1shape, dev)
                 side.keep(dw1)
-                L.check(_wgrad(d1, dy, h, alpha2, dw1, None, ws, nb1, s2), "unit k1 wgrad")
-                if g1w is not None:
-                    dw1, dg1 = _wn_bwd(dw1, v1, g1w, n1, s2, s1w, s1g)
+                if g1w is None:
+                    L.check(_wgrad(d1, dy, h, alpha2, dw1, None, ws, nb1, s2), "unit k1 wgrad")
+                else:
+                    dw1, dg1 = _wgrad_wn(d1, dy, h, alpha2, dw1, None, v1, g1w, n1, ws, nb1, s2, s1w, s1g, side)
                     side.keep(dw1, dg1)
             if ctx.needs_input_grad[1] or (g3w is not None and ctx.needs_input_grad[2]):
                 s3w, s3g, s1w, s1g = ctx.slots
                 dw3 = _grad_out(s3w if g3w is None else None, ctx.w3shape, dev)
                 side.keep(dw3)
-                L.check(_wgrad(d3, dh, x, alpha0, dw3, None, ws, nb3, s2), "unit k3 wgrad")
-                if g3w is not None:
-                    dw3, dg3 = _wn_bwd(dw3, v3, g3w, n3, s2, s3w, s3g)
+                if g3w is None:
+                    L.check(_wgrad(d3, dh, x, alpha0, dw3, None, ws, nb3, s2), "unit k3 wgrad")
+                else:
+                    dw3, dg3 = _wgrad_wn(d3, dh, x, alpha0, dw3, None, v3, g3w, n3, ws, nb3, s2, s3w, s3g, side)
                     side.keep(dw3, dg3)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -1324,6 +1376,48 @@ def feature_matching(features, weights, relative: bool) -> Tensor:
     """``features``: unsplit discriminator feature maps (2B, ...), real half first; ``weights``: one factor per map (the
     1 / (maps of its discriminator x discriminators) of rave/model.py:359-372)."""
     return _FeatureMatchingFn.apply(bool(relative), tuple(float(w) for w in weights), *features)
+
+
+class _LossCombineFn(torch.autograd.Function):
+    """(total, scaled): scaled_i = w1_i * value_i, total = sum_i scaled_i * w2_i -- rh_loss_combine_fwd/bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, meta, *vals):
+        w1, w1_dev, w2 = meta
+        n = len(vals)
+        vals = [_chk(v, "loss term") for v in vals]
+        if any(v.numel() != 1 for v in vals):
+            raise RuntimeError("rave_amd loss_combine: every term must be a scalar tensor")
+        dev = vals[0].device
+        arr = (L.LossItem * n)()
+        for a, v, a1, d1, a2 in zip(arr, vals, w1, w1_dev, w2):
+            a.value, a.w1_dev, a.w1, a.w2 = L.ptr(v), (L.ptr(d1) if d1 is not None else None), float(a1), float(a2)
+        scaled = torch.empty(n, device=dev, dtype=torch.float32)
+        total = torch.empty((), device=dev, dtype=torch.float32)
+        L.check(L.lib.rh_loss_combine_fwd_f32(arr, n, L.ptr(scaled), L.ptr(total), L.stream()), "loss_combine_fwd")
+        ctx.arr, ctx.n = arr, n
+        ctx.keep = (vals, [d for d in w1_dev if d is not None])        # (the table holds raw pointers)
+        ctx.mark_non_differentiable(scaled)
+        return total, scaled
+
+    @staticmethod
+    def backward(ctx, g, _g_scaled):
+        g = _chk(g, "grad").reshape(1)
+        grads = torch.empty(ctx.n, device=g.device, dtype=torch.float32)
+        L.check(L.lib.rh_loss_combine_bwd_f32(ctx.arr, ctx.n, L.ptr(g), L.ptr(grads), L.stream()), "loss_combine_bwd")
+        return (None,) + tuple(grads[i].reshape(v.shape) if ctx.needs_input_grad[i + 1] else None
+                               for i, v in enumerate(ctx.keep[0]))
+
+
+def loss_combine(values, w1, w2, w1_dev=None):
+    """The generator loss of a step in one launch each way (rave/model.py:336-344, 392-412): ``scaled[i] = w1[i] * values[i]``
+    (or ``values[i] * w1_dev[i]`` where a device scalar is given -- the captured step's beta_factor) and
+    ``total = sum_i scaled[i] * w2[i]`` in term order, every product rounded on its own: the bits of the reference's
+    ``weights[k] * v`` ... ``loss_gen_value += v * self.weights.get(k, 1.)`` chain.  Returns (total, scaled); ``scaled`` is for
+    logging (not differentiable)."""
+    n = len(values)
+    w1_dev = list(w1_dev) if w1_dev is not None else [None] * n
+    return _LossCombineFn.apply((tuple(float(a) for a in w1), tuple(w1_dev), tuple(float(a) for a in w2)), *values)
 
 
 class _AvgPool2Fn(torch.autograd.Function):

@@ -637,3 +637,128 @@ def test_gradient_accumulation_over_two_backward_calls_with_the_side_stream(dev)
         got = run(1, 2)
         for a, b in zip(got, ref2):
             assert torch.equal(a, b)
+
+
+WN_TAIL_CASES = [
+    # (name, batch, c_in, c_out, length, kernel, geometry kwargs, transposed)
+    ("unit_k3_c96", 8, 96, 96, 4096, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2), False),
+    ("unit_k1_c96", 8, 96, 96, 4096, 1, dict(act=1, slope=0.2), False),
+    ("unit_k3_c384", 8, 384, 384, 256, 3, dict(dilation=9, pad_left=9, pad_right=9, act=1, slope=0.2), False),
+    ("unit_k3_c768_few_slices", 32, 768, 768, 64, 3, dict(dilation=1, pad_left=1, pad_right=1, act=1, slope=0.2), False),
+    ("down_192_384", 8, 192, 384, 1024, 8, dict(stride=4, pad_left=4, pad_right=0, act=1, slope=0.2), False),
+    ("up_768_384", 8, 768, 384, 64, 8, dict(stride=4, pad_left=2, pad_right=2, transposed=True, act=1, slope=0.2), True),
+    ("first_16_96_k7", 8, 16, 96, 4096, 7, dict(pad_left=3, pad_right=3), False),
+    ("odd_row_c_out_1", 4, 96, 1, 2048, 7, dict(pad_left=3, pad_right=3, act=1, slope=0.2), False),
+]
+
+
+@pytest.mark.parametrize("case", WN_TAIL_CASES, ids=[c[0] for c in WN_TAIL_CASES])
+def test_weight_gradient_through_weight_norm_in_one_launch_equals_the_two_launch_path(dev, case):
+    """rh_conv1d_bwd_weight_wn_f32 (K-slice reduction + torch._weight_norm backward in one launch, the summed dw never written;
+    rave/blocks.py:15-22 around every generator conv) against rh_conv1d_bwd_weight_f32 + rh_weight_norm_bwd_f32: the fused
+    kernel adds in the same order, so dv / dg must be the SAME BITS, in both kernel modes (bf16x6 and exact-f32 weight
+    gradient kernels produce different partial layouts / slice counts)."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    _, batch, c_in, c_out, length, k, kw, transposed = case
+    gen = torch.Generator().manual_seed(11)
+    geom = ConvGeom(**kw)
+    x = torch.randn(batch, c_in, length, generator=gen).to(dev)
+    v0 = (torch.randn(c_in, c_out, k, generator=gen) if transposed else torch.randn(c_out, c_in, k, generator=gen)).mul_(0.05).to(dev)
+    g0 = (torch.rand(v0.shape[0], 1, 1, generator=gen) + 0.5).to(dev)
+
+    def run(fused, x6):
+        with _Env(RH_WN_FUSED=fused, RH_WGRAD_X6=x6, RH_BWD_SIDE_STREAM=0):
+            v, g = v0.clone().requires_grad_(True), g0.clone().requires_grad_(True)
+            y = R.conv1d(x, v, None, geom=geom, weight_g=g)
+            cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(12)).to(dev)
+            y.backward(cot)
+            torch.cuda.synchronize()
+            return v.grad.clone(), g.grad.clone()
+
+    from rave_amd import _lib as L
+    for x6 in (1, 0):
+        n0 = L.lib.rh_conv1d_bwd_weight_wn_fused_launches()
+        dv2, dg2 = run(0, x6)
+        assert L.lib.rh_conv1d_bwd_weight_wn_fused_launches() == n0
+        dv1, dg1 = run(1, x6)
+        if case[0] != "odd_row_c_out_1" and x6:     # (one output row: the exact-f32 kernel's plan may not split K)
+            assert L.lib.rh_conv1d_bwd_weight_wn_fused_launches() == n0 + 1, "the one-launch form did not run"
+        assert torch.isfinite(dv1).all() and torch.isfinite(dg1).all()
+        assert torch.equal(dv1, dv2), (x6, rel_l2(dv1, dv2))
+        assert torch.equal(dg1, dg2), (x6, rel_l2(dg1, dg2))
+
+
+def test_collected_weight_norm_backward_equals_one_launch_per_layer(dev):
+    """rave_amd.ops._WN_PENDING: on the weight-gradient side stream the weight-norm backward of every normalization(conv)
+    (rave/blocks.py:15-22) is collected and run as ONE launch when the branch is joined (rh_weight_norm_bwd_batched_f32).
+    A chain of weight-normed convs + a fused residual unit, backward through all of them: gradients with the batch on ==
+    batch off == side stream off, bit for bit, over repeated trials (a missing join would show as garbage / differing bits);
+    a second backward() without zero_grad (no side stream then) still accumulates correctly."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    gen = torch.Generator().manual_seed(21)
+    C_ = 96
+    gk3 = ConvGeom(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2)
+    gk1 = ConvGeom(act=1, slope=0.2)
+    gdn = ConvGeom(stride=4, pad_left=4, pad_right=0, act=1, slope=0.2)
+    gup = ConvGeom(stride=4, pad_left=2, pad_right=2, transposed=True, act=1, slope=0.2)
+    x = torch.randn(8, C_, 2048, generator=gen).to(dev)
+    shapes = [(C_, C_, 3), (C_, C_, 1), (2 * C_, C_, 8), (2 * C_, C_, 8), (C_, C_, 3), (C_, C_, 1)]
+    v0 = [(torch.randn(*s, generator=gen) * 0.05).to(dev) for s in shapes]
+    g0 = [(torch.rand(s[0], 1, 1, generator=gen) + 0.5).to(dev) for s in shapes]
+
+    def run(batch, side, passes=1):
+        with _Env(RH_WN_BATCH=batch, RH_BWD_SIDE_STREAM=side):
+            vs = [t.clone().requires_grad_(True) for t in v0]
+            gs = [t.clone().requires_grad_(True) for t in g0]
+            for _ in range(passes):
+                h = R.conv1d(x, vs[0], None, geom=gk3, weight_g=gs[0])
+                h = R.conv1d(h, vs[1], None, geom=gk1, weight_g=gs[1])
+                h = R.conv1d(h, vs[2], None, geom=gdn, weight_g=gs[2])          # 96 -> 192, stride 4
+                h = R.conv1d(h, vs[3], None, geom=gup, weight_g=gs[3])          # 192 -> 96, transposed
+                h = R.residual_unit(h, vs[4], vs[5], gk3, gk1, w3_g=gs[4], w1_g=gs[5])
+                (h * h).mean().backward()
+            torch.cuda.synchronize()
+            return [t.grad.clone() for t in vs + gs]
+
+    ref = run(0, 0)
+    assert all(torch.isfinite(t).all() and t.abs().max() > 0 for t in ref)
+    for _ in range(4):
+        for a, b in zip(run(1, 1), ref):
+            assert torch.equal(a, b)
+    for a, b in zip(run(0, 1), ref):
+        assert torch.equal(a, b)
+    two = run(1, 1, passes=2)
+    for a, b in zip(two, ref):
+        assert rel_l2(a, 2 * b) < 1e-6
+
+
+def test_loss_combine_is_the_aten_chain_bit_for_bit(dev):
+    """rave_amd.ops.loss_combine (one launch each way) vs the reference's scalar chain -- `weights[k] * v`, `reg * beta`,
+    `loss_gen_value += v * self.weights.get(k, 1.)`, backward() (rave/model.py:336-344, 392-412): logged terms, total and the
+    gradient reaching every term are the same bits, with a host or a device first factor."""
+    from rave_amd import ops as R
+    gen = torch.Generator().manual_seed(3)
+    for trial in range(20):
+        n = 7
+        raw = [(torch.randn((), generator=gen) * 10 ** float(torch.randint(-3, 3, (1,), generator=gen))).to(dev) for _ in range(n)]
+        w1 = [1., 1., 0.3, 20, 1.7, 1., 1e-3]
+        w2 = [1., 1., 1., 1., 0.123, 1., 7.]
+        beta = torch.full((), 0.37 + 0.01 * trial, device=dev)
+        a = [t.clone().requires_grad_(True) for t in raw]
+        logged_ref = [w * t for w, t in zip(w1, a)]
+        logged_ref[2] = a[2] * beta                      # `reg * beta_device`
+        total_ref = 0.
+        for t, w in zip(logged_ref, w2):
+            total_ref += t * w
+        total_ref.backward()
+        b = [t.clone().requires_grad_(True) for t in raw]
+        w1_dev = [None] * n
+        w1_dev[2] = beta
+        total, scaled = R.loss_combine(b, w1, w2, w1_dev)
+        total.backward()
+        assert torch.equal(total.detach(), total_ref.detach())
+        for i in range(n):
+            assert torch.equal(scaled[i], logged_ref[i].detach()), i
+            assert torch.equal(b[i].grad, a[i].grad), i
