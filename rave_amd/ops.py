@@ -332,6 +332,10 @@ def _side_stream(device):
 # autograd are filled by that launch: like every gradient of the side stream they are valid once the branch is joined.
 # RH_WN_BATCH=0: one launch per layer, at once.
 _WN_PENDING = []
+import os as _os
+_WN_BATCH_MAX = int(_os.environ.get("RH_WN_BATCH_MAX", "64"))      # layers per launch (= the table size of the kernel): a pass with more pending layers launches early, on the side stream.
+#                         (16 / 8 per launch -- so that only the last, small layers are left for the join -- measured the same
+#                         step time as one launch at the join: 10.18-10.24 vs 10.16-10.20 ms)
 
 
 def _wn_batch_enabled() -> bool:
@@ -540,6 +544,8 @@ def _wgrad_wn(d, dy, x, alpha, dw, db, v, g, norms, ws, nbytes, s, slot_v=None, 
         # (aliases of dv / dg keep the storage alive until the batch has run; the tensor OBJECTS handed to autograd must have
         # no other holder, or AccumulateGrad clones -- i.e. reads -- them instead of adopting them)
         _WN_PENDING.append((dw, v, g, norms, dv.detach(), dg.detach()))
+        if len(_WN_PENDING) >= _WN_BATCH_MAX:      # (we are on the side stream here: the batch runs beside the data-gradient chain)
+            _flush_wn_pending(s)
         return dv, dg
     L.check(L.lib.rh_conv1d_bwd_weight_wn_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(v), L.ptr(g), L.ptr(norms),
                                               L.ptr(dw), L.ptr(dv), L.ptr(dg), L.ptr(db), L.ptr(ws), nbytes, s),
