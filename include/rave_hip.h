@@ -396,6 +396,12 @@ int64_t rh_stft_loss_workspace_bytes(int32_t n_fft, int32_t t_len, int64_t rows)
 int rh_stft_loss_fwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,
                          int32_t t_len, int32_t n_fft, float eps, float* sums, void* workspace, int64_t workspace_bytes,
                          rh_stream_t stream);
+/* sums == NULL above: the per-workgroup partials stay in `workspace` (rh_stft_loss_workspace_bytes of them) and ONE call
+ * finalizes all scales of a distance: sums (n_scales x 3, as above) and total = sum_s sums[s][0] / sums[s][1] + sums[s][2] *
+ * inv_n[s] (AudioDistanceV1 over MultiScaleSTFT, rave/core.py:269-344) -- one launch instead of n_scales + 1 between the
+ * forward and the backward pass; same reduction order, same bits.  partials[s] / partial_bytes[s]: HOST arrays. */
+int rh_stft_loss_finalize_all_f32(const float* const* partials, const int64_t* partial_bytes, int32_t n_scales,
+                                  const float* inv_n, float* sums, float* total, rh_stream_t stream);
 int rh_stft_loss_bwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,
                          int32_t t_len, int32_t n_fft, float eps, const float* sums, const float* grad_out, float* dx,
                          float* dy, int32_t accumulate, rh_stream_t stream);

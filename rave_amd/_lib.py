@@ -140,6 +140,7 @@ def _load() -> C.CDLL:
         "rh_stft_loss_plan_info": ([I32, I32, I64, C.POINTER(I64)], C.c_int),
         "rh_stft_loss_workspace_bytes": ([I32, I32, I64], I64),
         "rh_stft_loss_fwd_f32": ([P, P, P, P, I64, I32, I32, F, P, P, I64, P], C.c_int),
+        "rh_stft_loss_finalize_all_f32": ([C.POINTER(C.c_void_p), C.POINTER(I64), I32, P, P, P, P], C.c_int),
         "rh_stft_loss_bwd_f32": ([P, P, P, P, I64, I32, I32, F, P, P, P, P, I32, P], C.c_int),
         "rh_spectral_distance_workspace_bytes": ([], I64),
         "rh_spectral_distance_fwd_f32": ([P, P, I64, F, P, P, I64, P], C.c_int),

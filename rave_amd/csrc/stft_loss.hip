@@ -304,6 +304,37 @@ __global__ __launch_bounds__(256) void stft_loss_finalize_kernel(const float* __
     }
 }
 
+// The ordered finalize of ALL scales of one distance + the sum over the scales (misc.hip: spectral_total_kernel's formula) in
+// one launch: per distance 5 finalize launches + 1 total on the critical path between forward and backward become 1.  One
+// workgroup walks the scales with the same reduction as the kernel above (same bits).
+constexpr int kStftMaxScales = 8;
+struct StftFinTable {
+    const float* part[kStftMaxScales];
+    int nblocks[kStftMaxScales];
+    int count;
+};
+__global__ __launch_bounds__(256) void stft_loss_finalize_all_kernel(const StftFinTable tb, const float* __restrict__ inv_n,
+                                                                     float* __restrict__ sums, float* __restrict__ out) {
+    __shared__ float red[4];
+    float d = 0.f;
+    for (int sc = 0; sc < tb.count; ++sc) {
+        const float* __restrict__ part = tb.part[sc];
+        const int nblocks = tb.nblocks[sc];
+        float t[3];
+        for (int k = 0; k < 3; ++k) {
+            float s = 0.f;
+            for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i * 3 + k];
+            t[k] = wg_sum(s, red);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            sums[3 * sc] = t[0]; sums[3 * sc + 1] = t[1]; sums[3 * sc + 2] = t[2];
+            d += t[0] / t[1] + t[2] * inv_n[sc];
+        }
+    }
+    if (threadIdx.x == 0) out[0] = d;
+}
+
 template <int N>
 __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
     typedef Fft<N> F;
@@ -562,7 +593,7 @@ extern "C" int64_t rh_stft_loss_workspace_bytes(int32_t n_fft, int32_t t_len, in
 extern "C" int rh_stft_loss_fwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,
                                     int32_t t_len, int32_t n_fft, float eps, float* sums, void* workspace,
                                     int64_t workspace_bytes, rh_stream_t stream) {
-    RH_REQUIRE(x && y && window && twiddle && sums && workspace, RH_ERR_INVALID, "stft_loss_fwd: null pointer");
+    RH_REQUIRE(x && y && window && twiddle && workspace, RH_ERR_INVALID, "stft_loss_fwd: null pointer");
     RH_REQUIRE(shape_ok(n_fft, n_fft / 4, t_len, rows), RH_ERR_UNSUPPORTED, "stft_loss_fwd: unsupported geometry (n_fft %d, t %d)", n_fft, t_len);
     RH_REQUIRE(workspace_bytes >= rh_stft_loss_workspace_bytes(n_fft, t_len, rows), RH_ERR_WORKSPACE, "stft_loss_fwd: workspace too small");
     StftP p = {};
@@ -579,10 +610,26 @@ extern "C" int rh_stft_loss_fwd_f32(const float* x, const float* y, const float*
         case 1024: rc = launch_fwd<1024>(p, wx, (hipStream_t)stream); break;
         default: rc = launch_fwd<2048>(p, wx, (hipStream_t)stream); break;
     }
-    if (rc) return rc;
+    if (rc || !sums) return rc;         // sums == NULL: the partials stay in `workspace` for rh_stft_loss_finalize_all_f32
     hipLaunchKernelGGL(stft_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                        (int)(rows * wx), sums);
     return rh_check_launch("stft_loss_finalize");
+}
+
+extern "C" int rh_stft_loss_finalize_all_f32(const float* const* partials, const int64_t* partial_bytes, int32_t n_scales,
+                                             const float* inv_n, float* sums, float* total, rh_stream_t stream) {
+    RH_REQUIRE(partials && partial_bytes && inv_n && sums && total && n_scales > 0 && n_scales <= kStftMaxScales, RH_ERR_INVALID,
+               "stft_loss_finalize_all: bad arguments (1 .. %d scales)", kStftMaxScales);
+    StftFinTable tb;
+    for (int i = 0; i < n_scales; ++i) {
+        RH_REQUIRE(partials[i] && partial_bytes[i] > 0 && partial_bytes[i] % 12 == 0 && partial_bytes[i] / 12 < 0x7fffffffl, RH_ERR_INVALID,
+                   "stft_loss_finalize_all: bad partials of scale %d", i);
+        tb.part[i] = partials[i];
+        tb.nblocks[i] = (int)(partial_bytes[i] / 12);
+    }
+    tb.count = n_scales;
+    hipLaunchKernelGGL(stft_loss_finalize_all_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tb, inv_n, sums, total);
+    return rh_check_launch("stft_loss_finalize_all");
 }
 
 extern "C" int rh_stft_loss_bwd_f32(const float* x, const float* y, const float* window, const float* twiddle, int64_t rows,

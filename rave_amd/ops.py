@@ -1119,6 +1119,11 @@ def stft_distance(frames_x: Tensor, frames_y: Tensor, eps: float) -> Tensor:
     return _StftDistanceFn.apply(frames_x, frames_y, eps)
 
 
+def _stft_one_finalize() -> bool:
+    import os
+    return os.environ.get("RH_STFT_ONE_FINALIZE", "1") != "0"
+
+
 class _MultiScaleStftDistanceFn(torch.autograd.Function):
     """AudioDistanceV1 over ALL scales of MultiScaleSTFT as one autograd node (rave/core.py:269-344): per scale the HIP
     framing kernel, rocFFT R2C and the fused distance kernel; the sum over the scales in one tiny launch; backward: per
@@ -1141,19 +1146,27 @@ class _MultiScaleStftDistanceFn(torch.autograd.Function):
             # transform inside the kernel (stft_loss.hip): nothing but the two waveforms is read, nothing but 3 sums per
             # scale written; the backward recomputes the spectra from the saved waveforms
             inv_n = []
+            one_finalize = ns <= 8 and _stft_one_finalize()
+            parts = []
             for i, (n_fft, win) in enumerate(zip(scales, windows)):
                 win = _chk(win, "window")
                 nbytes = L.lib.rh_stft_loss_workspace_bytes(n_fft, t, rows)
                 ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
                 L.check(L.lib.rh_stft_loss_fwd_f32(L.ptr(x), L.ptr(y), L.ptr(win), L.ptr(_twiddle(n_fft, dev)), rows, t, n_fft, eps,
-                                                   sums[i].data_ptr(), L.ptr(ws), nbytes, s), "stft_loss_fwd")
+                                                   None if one_finalize else sums[i].data_ptr(), L.ptr(ws), nbytes, s), "stft_loss_fwd")
+                parts.append((ws, nbytes))
                 inv_n.append(1.0 / (rows * (t // (n_fft // 4) + 1) * (n_fft // 2 + 1)))
             key = (tuple(inv_n), str(dev))
             if key not in _INV_N and not torch.cuda.is_current_stream_capturing():
                 _INV_N[key] = torch.tensor(inv_n, dtype=torch.float32, device=dev)
             inv = _inv_n_cached(tuple(inv_n), dev)
             out = torch.empty((), device=dev, dtype=torch.float32)
-            L.check(L.lib.rh_spectral_total_f32(L.ptr(sums), L.ptr(inv), ns, L.ptr(out), s), "spectral_total")
+            if one_finalize:       # the ordered finalize of every scale + the sum over the scales: one launch
+                pp = (C.c_void_p * ns)(*[w.data_ptr() for w, _ in parts])
+                nb = (C.c_int64 * ns)(*[b for _, b in parts])
+                L.check(L.lib.rh_stft_loss_finalize_all_f32(pp, nb, ns, L.ptr(inv), L.ptr(sums), L.ptr(out), s), "stft_loss_finalize_all")
+            else:
+                L.check(L.lib.rh_spectral_total_f32(L.ptr(sums), L.ptr(inv), ns, L.ptr(out), s), "spectral_total")
             ctx.save_for_backward(sums, *windows, x, y)
             ctx.meta = (rows, t, float(eps), tuple(int(v) for v in scales))
             ctx.fused = True

@@ -192,3 +192,27 @@ def test_stft_loss_unsupported_geometry_takes_the_rocfft_path():
     d, gx, gy = _run(x, y, (4096, 512), ws, 1e-2, True)                  # 4096 is not an in-kernel size: whole node on rocFFT
     dr, gxr, gyr = _ref(x, y, (4096, 512), ws, 1e-2)
     assert abs(float(d) - float(dr)) <= 2e-6 * abs(float(dr))
+
+
+@pytest.mark.parametrize("rows,t,scales", [(32, 4096, SCALES), (4, 65536, SCALES), (3, 5000, (2048, 128))])
+def test_one_finalize_launch_for_all_scales_is_bit_identical_to_one_per_scale(rows, t, scales):
+    """rh_stft_loss_finalize_all_f32 (every scale's ordered finalize + the sum over the scales in one launch) against
+    rh_stft_loss_fwd_f32's own finalize per scale + rh_spectral_total_f32: same distance, same gradients, bit for bit."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(rows, t, generator=g).to(dev)
+    y = (x.cpu() + 0.3 * torch.randn(rows, t, generator=g)).to(dev)
+    ws = _windows(scales, dev)
+    old = os.environ.get("RH_STFT_ONE_FINALIZE")
+    try:
+        os.environ["RH_STFT_ONE_FINALIZE"] = "0"
+        a = _run(x, y, scales, ws, 1e-7, True)
+        os.environ["RH_STFT_ONE_FINALIZE"] = "1"
+        b = _run(x, y, scales, ws, 1e-7, True)
+    finally:
+        if old is None:
+            os.environ.pop("RH_STFT_ONE_FINALIZE", None)
+        else:
+            os.environ["RH_STFT_ONE_FINALIZE"] = old
+    assert torch.isfinite(b[0]) and float(b[0]) > 0
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
