@@ -34,7 +34,7 @@ F32_MFMA_PEAK = 157.3e12   # FLOP/s (f32-input MFMA == f32 vector peak)
 X6_MFMA_PEAK = 2.5e15 / 6  # FLOP/s f32-equivalent of the bf16 matrix cores at 6 MFMAs per product block (conv_x6)
 # what a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on this part with random operands: 20.1 ns per MFMA and
 # SIMD (one wave per SIMD; 17.9 with two) -- the chip is POWER-limited there, the shader clock reads 1.64 GHz instead of
-# 2.4 (tools/probe/mfma_clock.hip, profiles/round3_probe_mfma_clock.txt)
+# 2.4 (tools/probe/mfma_clock.hip, profiles/round4_probe_mfma_clock.txt)
 X6_MFMA_SUSTAINED = 32768 * 1024 / 17.9e-9 / 6
 
 
@@ -430,7 +430,7 @@ def main():
             "algorithmic_gflop_per_launch": fl / n / 1e9,
             "timing_note": "avg_launch_ms = the kernel's own duration: every launch is dispatched with a pair of HIP events as "
                            "its start / stop events (rh_set_kernel_events -> hipExtLaunchKernelGGL, on the launch stream), the "
-                           "timestamps rocprofv3 reads -- compare profiles/round3_kernel_stats_step_b32.md (rocprofv3 "
+                           "timestamps rocprofv3 reads -- compare profiles/round4_kernel_stats_step_b32.md (rocprofv3 "
                            "--kernel-trace --stats of `bench.py --no-graph`, RH_BWD_SIDE_STREAM=0).  Eager replays of the step "
                            "with the side stream off (one kernel at a time); the timed region itself overlaps the "
                            "weight-gradient branch on a second stream.  avg_call_ms = event bracket around the whole C-ABI "
@@ -451,7 +451,7 @@ def main():
                                         "clock reads 1.64 GHz (s_memtime / wall) and one MFMA takes 20.1 ns per SIMD (17.9 with two "
                                         "waves) = 0.67-0.75 of nominal; up to 2 independent VALU per MFMA gap cost nothing in wall "
                                         "time, each further one ~1.2 ns (tools/probe/mfma_clock.hip, "
-                                        "profiles/round3_probe_mfma_clock.txt).  frac_vs_sustained_mfma_rate prices the kernel "
+                                        "profiles/round4_probe_mfma_clock.txt).  frac_vs_sustained_mfma_rate prices the kernel "
                                         "against that measured rate")
         out["kernel_families"] = {k: {"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "call_ms_per_step": v[4] / reps,
                                       "tflops": v[1] / (v[3] * 1e-3) / 1e12,
