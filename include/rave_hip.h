@@ -436,19 +436,23 @@ int rh_loss_combine_bwd_f32(const rh_loss_item* items, int32_t n_items, const fl
                             rh_stream_t stream);
 
 /* Adam step over many tensors (torch.optim.Adam, weight_decay = 0, amsgrad = False; rave/model.py:226-233): for every
- * item  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).
+ * item  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * with t = the item's OWN step count (torch keeps one per parameter: a parameter whose first gradient comes later -- the
+ * v1 generator's noise branch after the warm-up, rave/blocks.py:418 -- starts at t = 1).
  * `items` is a HOST array (the pointers inside are device pointers; it is consumed during the call: the tables travel in
- * the kernel arguments, so the call can be recorded into a hipGraph); `lr` and `step` are device scalars -- the call first
- * advances step[0] by one (t) -- and `aux` is 2 floats of device scratch. */
+ * the kernel arguments, so the call can be recorded into a hipGraph); `lr` and every `step` are device scalars -- the call
+ * first advances each DISTINCT step counter among the items by one (items may share a counter) -- and `aux` is
+ * 2 * n_items floats of device scratch (the bias corrections per counter). */
 typedef struct rh_adam_item {
     float* p;
     const float* g;
     float* m;
     float* v;
     int64_t n;
+    float* step;
 } rh_adam_item;
 int rh_adam_step_f32(const rh_adam_item* items, int32_t n_items, const float* lr, float beta1, float beta2, float eps,
-                     float* step, float* aux, rh_stream_t stream);
+                     float* aux, rh_stream_t stream);
 
 /* Feature-matching distance of the GAN phase (rave/model.py:359-372 over rave/core.py:236-252, norm "L1") on UNSPLIT
  * discriminator feature maps: item i is a dense f32 tensor of 2 * half elements, the real half of the batch first;

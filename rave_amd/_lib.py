@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
 
 class AdamItem(C.Structure):
     """Mirror of ``rh_adam_item`` (include/rave_hip.h)."""
-    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64), ("step", C.c_void_p)]
 
 
 class WnBwdItem(C.Structure):
@@ -130,7 +130,7 @@ def _load() -> C.CDLL:
         "rh_reparam_bwd_f32": ([P, P, P, P, I32, I32, I32, P, P], C.c_int),
         "rh_loss_combine_fwd_f32": ([C.POINTER(LossItem), I32, P, P, P], C.c_int),
         "rh_loss_combine_bwd_f32": ([C.POINTER(LossItem), I32, P, P, P], C.c_int),
-        "rh_adam_step_f32": ([C.POINTER(AdamItem), I32, P, F, F, F, P, P, P], C.c_int),
+        "rh_adam_step_f32": ([C.POINTER(AdamItem), I32, P, F, F, F, P, P], C.c_int),
         "rh_set_kernel_events": ([P, P], C.c_int),
         "rh_kernel_events_used": ([], C.c_int),
         "rh_event_create": ([C.POINTER(C.c_void_p)], C.c_int),

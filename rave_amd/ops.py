@@ -310,6 +310,7 @@ def _dgrad(d, dy, wp, x, alpha, add, dx, s):
 # into the step's hipGraph the two streams become parallel branches of the graph.
 _SIDE = {}
 _SIDE_PENDING = [None]
+_SIDE_HOLD = []        # incoming gradient tensors the branch still reads (see _OnSide): released when the branch is joined
 
 
 def _side_enabled() -> bool:
@@ -365,6 +366,7 @@ def join_side_streams() -> None:
         main.wait_stream(side)
         torch.cuda.current_stream().wait_stream(side)
         _SIDE_PENDING[0] = None
+        _SIDE_HOLD.clear()
 
 
 def _note_use(ctx, *params) -> None:
@@ -405,9 +407,15 @@ class _OnSide:
     """``with _OnSide(device, tensors...)``: the body is enqueued on the side stream after everything already enqueued on
     the current stream; ``tensors`` are kept alive for it (caching-allocator stream bookkeeping)."""
 
-    def __init__(self, device, *tensors, allow: bool = True):
+    def __init__(self, device, *tensors, allow: bool = True, hold=()):
+        """``hold``: gradient tensors RECEIVED from autograd that the body reads.  The same tensor object may sit in another
+        node's input buffer (``y = conv(x) + other``: AddBackward hands ONE tensor to both branches), and autograd
+        accumulates into a buffered gradient IN PLACE once it is the only holder -- on the compute stream, while the side
+        stream still reads it.  A reference kept until the branch is joined makes that accumulation take the
+        out-of-place form."""
         self.device = device
         self.tensors = [t for t in tensors if t is not None]
+        self.hold = [t for t in hold if t is not None]
         import os
         self.active = allow and _side_enabled()
 
@@ -430,6 +438,9 @@ class _OnSide:
         self.ctx.__exit__(*exc)
         for t in self.tensors:
             t.record_stream(self.side)
+        import os
+        if os.environ.get("RH_SIDE_HOLD", "1") != "0":      # (0: the unprotected form, for the test that shows the race)
+            _SIDE_HOLD.extend(self.hold)
         if _SIDE_PENDING[0] is None:
             _SIDE_PENDING[0] = (self.main, self.side)
             try:        # end of this backward pass: the compute stream waits for the branch
@@ -593,6 +604,7 @@ class _ConvFn(torch.autograd.Function):
         # on as the residual's gradient below, and autograd accumulates INTO such tensors in place; (b) the parameters'
         # gradients are adopted unread (one pending use each)
         side_ok = _single_use(ctx) and not (ctx.has_res and ctx.needs_input_grad[5])
+        dy_in = dy if y_act is None else None      # (with an output activation the branch reads gpre, a tensor of this node)
         if y_act is not None:      # output activation: every gradient below is taken w.r.t. the pre-activation
             gpre = torch.empty_like(dy)
             L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y_act), d.out_act, d.out_slope, dy.numel(), L.ptr(gpre), s),
@@ -611,7 +623,7 @@ class _ConvFn(torch.autograd.Function):
                 db = _grad_out(slot_b, (d.c_out,), dy.device)
             nbytes = L.lib.rh_conv1d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
-            with _OnSide(dy.device, dy, x, ws, dw, db, v, g, norms, alpha, allow=side_ok) as side:
+            with _OnSide(dy.device, dy, x, ws, dw, db, v, g, norms, alpha, allow=side_ok, hold=(dy_in,)) as side:
                 s2 = L.stream()
                 if g is None:
                     L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s2), "conv1d_bwd_weight")
@@ -721,7 +733,7 @@ class _ResidualUnitFn(torch.autograd.Function):
         ws = torch.empty(max(nb1, nb3, 4) // 4, device=dev)
         # both weight-gradient branches (operands: dy, h, dh, x -- all produced by now) may run beside the k3 data gradient
         # (dy is only read here -- the residual gradient is added inside the k3 data-gradient kernel -- and dx is a new tensor)
-        with _OnSide(dev, dy, h, dh, x, ws, v3, g3w, n3, v1, g1w, n1, alpha0, alpha2, allow=_single_use(ctx)) as side:
+        with _OnSide(dev, dy, h, dh, x, ws, v3, g3w, n3, v1, g1w, n1, alpha0, alpha2, allow=_single_use(ctx), hold=(dy,)) as side:
             s2 = L.stream()
             if ctx.needs_input_grad[3] or (g1w is not None and ctx.needs_input_grad[4]):
                 s3w, s3g, s1w, s1g = ctx.slots

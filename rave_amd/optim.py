@@ -1,8 +1,9 @@
 """Adam for the generator / discriminator parameters on the HIP kernel of rave_amd/csrc/adam.hip (rh_adam_step_f32):
 ``torch.optim.Adam(params, lr, betas)`` semantics (weight_decay = 0, amsgrad = False -- what rave/model.py:226-233
-configures), same ``state`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so ``state_dict()`` round-trips
-with torch's Adam), step counter and learning rate in device memory (always "capturable": the step records into a
-hipGraph).  Plumbing beside the hot path: one pass over parameters, gradients and both moments at HBM speed instead of
+configures), same ``state`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter -- every parameter counts its
+OWN steps, as torch's does: one that gets its first gradient late starts its bias corrections at 1 -- so ``state_dict()``
+round-trips with torch's Adam), step counters and learning rate in device memory (always "capturable": the step records
+into a hipGraph).  Plumbing beside the hot path: one pass over parameters, gradients and both moments at HBM speed instead of
 torch's fused multi-tensor kernel at 1.6 TB/s."""
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: bad hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self._tables = {}
-        self._gs = {}          # per group: device step counter / scratch (kept out of param_groups: state_dict() stays torch's)
+        self._gs = {}          # per group: device scratch (kept out of param_groups: state_dict() stays torch's)
 
     def _group_state(self, gi: int, group):
         ps = [p for p in group["params"] if p.requires_grad]
@@ -27,9 +28,9 @@ class FusedAdam(torch.optim.Optimizer):
             return None
         dev = ps[0].device
         gs = self._gs.setdefault(gi, {})
-        if "step" not in gs:
-            gs["step"] = torch.zeros((), device=dev, dtype=torch.float32)
-            gs["aux"] = torch.zeros(2, device=dev, dtype=torch.float32)
+        if "dev" not in gs:
+            gs["dev"] = dev
+            gs["aux"] = None           # 2 floats per live parameter (bias corrections per step counter)
             gs["lr_dev"] = None
         return gs
 
@@ -56,13 +57,15 @@ class FusedAdam(torch.optim.Optimizer):
                     g = p.grad = g.contiguous()
                 st = self.state[p]
                 if not st:
-                    st["step"] = gs["step"]                      # one counter per group, aliased by every parameter
+                    st["step"] = torch.zeros((), device=p.device, dtype=torch.float32)     # per parameter, as torch's Adam
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                elif st["step"] is not gs["step"]:                # after load_state_dict: adopt the loaded counter once
-                    gs["step"].copy_(st["step"].to(gs["step"].device, torch.float32).reshape(()))
-                    st["step"] = gs["step"]
-                live.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                else:
+                    t = st["step"]
+                    if not (torch.is_tensor(t) and t.device == p.device and t.dtype == torch.float32 and t.dim() == 0):
+                        # after load_state_dict of a foreign layout (CPU / int / 1-element counters): one device scalar
+                        st["step"] = torch.as_tensor(float(t), dtype=torch.float32).to(p.device).reshape(())
+                live.append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"]))
             if not live:
                 continue
             lr = group["lr"]
@@ -70,17 +73,23 @@ class FusedAdam(torch.optim.Optimizer):
                 lr_dev = lr
             else:                                               # a Python float: mirrored into a device scalar
                 if gs["lr_dev"] is None:
-                    gs["lr_dev"] = torch.empty((), device=gs["step"].device, dtype=torch.float32)
+                    gs["lr_dev"] = torch.empty((), device=gs["dev"], dtype=torch.float32)
                 gs["lr_dev"].fill_(float(lr))
                 lr_dev = gs["lr_dev"]
-            key = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()) for p, g, m, v in live)
+            key = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), t.data_ptr()) for p, g, m, v, t in live)
             tab = self._tables.get(gi)
             if tab is None or tab[0] != key:
                 arr = (L.AdamItem * len(live))()
-                for i, (p, g, m, v) in enumerate(live):
+                for i, (p, g, m, v, t) in enumerate(live):
                     arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                    arr[i].step = t.data_ptr()
                 tab = self._tables[gi] = (key, arr)
+            if gs["aux"] is None or gs["aux"].numel() < 2 * len(live):
+                if torch.cuda.is_current_stream_capturing() and gs["aux"] is not None:
+                    raise RuntimeError("rave_amd FusedAdam: more parameters received gradients inside a hipGraph capture than in "
+                                       "the eager steps before it")
+                gs["aux"] = torch.zeros(2 * len(live), device=gs["dev"], dtype=torch.float32)
             b1, b2 = group["betas"]
             L.check(L.lib.rh_adam_step_f32(tab[1], len(live), L.ptr(lr_dev), float(b1), float(b2), float(group["eps"]),
-                                           L.ptr(gs["step"]), L.ptr(gs["aux"]), L.stream()), "adam_step")
+                                           L.ptr(gs["aux"]), L.stream()), "adam_step")
         return loss

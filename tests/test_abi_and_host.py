@@ -469,3 +469,33 @@ def test_conv2d_x6_tile_plans_cover_every_geometry():
                     assert nphase == (1 if which == 0 else sh * sw)
                     assert wgs == -(-batch // nb) * tiles_r * tiles_q * (-(-m // (32 * tm))) * nphase
     assert checked > 500 and x6 > 200 and smallm > 20
+
+
+def test_table_entry_points_validate_their_host_tables_without_a_gpu():
+    """The by-value-table entry points of the backward tail (collected weight-norm backward, loss arithmetic, one finalize for
+    all STFT scales, Adam with per-parameter step counters): an empty table is a no-op, a malformed one is refused with a
+    message BEFORE anything is launched -- host logic only, no GPU needed."""
+    from rave_amd import _lib as L
+    assert L.lib.rh_weight_norm_bwd_batched_f32(None, 0, None) == 0
+    it = (L.WnBwdItem * 1)()
+    it[0].rows, it[0].cols = 4, 3                        # null pointers
+    assert L.lib.rh_weight_norm_bwd_batched_f32(it, 1, None) != 0 and b"bad item" in L.lib.rh_last_error()
+    assert L.lib.rh_weight_norm_bwd_batched_f32(None, 2, None) != 0
+    li = (L.LossItem * 17)()
+    buf = (C.c_float * 32)()
+    addr = C.addressof(buf)
+    assert L.lib.rh_loss_combine_fwd_f32(li, 0, addr, addr, None) != 0 and b"terms" in L.lib.rh_last_error()
+    assert L.lib.rh_loss_combine_fwd_f32(li, 17, addr, addr, None) != 0              # more than 16 terms
+    assert L.lib.rh_loss_combine_fwd_f32(li, 2, addr, addr, None) != 0 and b"null value" in L.lib.rh_last_error()
+    assert L.lib.rh_loss_combine_bwd_f32(li, 2, addr, addr, None) != 0
+    pp = (C.c_void_p * 9)(*([addr] * 9))
+    nb = (C.c_int64 * 9)(*([12] * 9))
+    assert L.lib.rh_stft_loss_finalize_all_f32(pp, nb, 9, addr, addr, addr, None) != 0 and b"scales" in L.lib.rh_last_error()
+    nb[0] = 10                                                                        # not a multiple of 3 floats
+    assert L.lib.rh_stft_loss_finalize_all_f32(pp, nb, 2, addr, addr, addr, None) != 0 and b"partials" in L.lib.rh_last_error()
+    assert L.lib.rh_adam_step_f32(None, 0, addr, 0.5, 0.9, 1e-8, addr, None) == 0    # no items: nothing launched
+    ai = (L.AdamItem * 1)()
+    ai[0].p = ai[0].g = ai[0].m = ai[0].v = addr
+    ai[0].n = 8                                                                       # no step counter
+    assert L.lib.rh_adam_step_f32(ai, 1, addr, 0.5, 0.9, 1e-8, addr, None) != 0 and b"bad item" in L.lib.rh_last_error()
+    assert L.lib.rh_conv1d_bwd_weight_wn_fused_launches() == 0

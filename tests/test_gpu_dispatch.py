@@ -445,7 +445,9 @@ def test_pqmf_second_generation_kernels_are_bit_identical_to_the_first(dev, t_le
 def test_fused_adam_kernel_matches_torch_adam(dev):
     """rave_amd.optim.FusedAdam (rh_adam_step_f32) against torch.optim.Adam on the same parameters / gradients over 6 steps
     with a changing learning rate: aligned and unaligned tensors, sizes around the 2048-element workgroup span, a parameter
-    without gradient; then a state_dict round trip into torch's Adam and back."""
+    without gradient, a parameter whose FIRST gradient arrives at the fourth step (torch counts steps per parameter: its
+    bias corrections start at 1 -- the v1 generator's noise branch after the warm-up, rave/blocks.py:418); then a
+    state_dict round trip into torch's Adam and back."""
     from rave_amd.optim import FusedAdam
     gen = torch.Generator().manual_seed(11)
     shapes = [(96, 96, 3), (7,), (2048,), (2049,), (1, 5, 1), (513, 37), (4096 + 3,), (1536, 768, 4)]
@@ -455,11 +457,13 @@ def test_fused_adam_kernel_matches_torch_adam(dev):
         n = torch.Size(s).numel()
         base.append(flat[o:o + n].reshape(s).clone())
         o += n
+    late0 = torch.randn(300, generator=gen)
     pa = [torch.nn.Parameter(b.clone().to(dev)) for b in base] + [torch.nn.Parameter(torch.zeros(5, device=dev))]
     pb = [torch.nn.Parameter(b.clone().to(dev)) for b in base] + [torch.nn.Parameter(torch.zeros(5, device=dev))]
+    late_a, late_b = torch.nn.Parameter(late0.clone().to(dev)), torch.nn.Parameter(late0.clone().to(dev))
     lr_a = torch.tensor(1e-3, device=dev)
-    oa = FusedAdam(pa, lr_a, (.5, .9))
-    ob = torch.optim.Adam(pb, 1e-3, (.5, .9))
+    oa = FusedAdam(pa + [late_a], lr_a, (.5, .9))
+    ob = torch.optim.Adam(pb + [late_b], 1e-3, (.5, .9))
     gbuf = torch.empty(sum(p.numel() for p in pa[:-1]) + 1, device=dev)
     for it in range(6):
         o = 1 if it % 2 else 0                       # alternate aligned / unaligned gradient storage
@@ -469,20 +473,25 @@ def test_fused_adam_kernel_matches_torch_adam(dev):
             a.grad.copy_(g)
             b.grad = g.clone()
             o += a.numel()
+        if it >= 3:
+            g = torch.randn(300, generator=gen).to(dev)
+            late_a.grad, late_b.grad = g.clone(), g.clone()
         lr = 1e-3 * (1.0 - 0.1 * it)
         lr_a.fill_(lr)
         ob.param_groups[0]["lr"] = lr
         oa.step(); ob.step()
-        for a, b in zip(pa, pb):
+        for a, b in zip(pa + [late_a], pb + [late_b]):
             assert rel_l2(a.detach(), b.detach()) < 2e-7 if b.abs().max() > 0 else torch.equal(a, b)
+    assert float(oa.state[late_a]["step"]) == 3.0 and float(ob.state[late_b]["step"]) == 3.0
+    assert not torch.equal(late_a.detach().cpu(), late0)
     for a, b in zip(pa[:-1], pb[:-1]):
         assert rel_l2(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-6
         assert rel_l2(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6
     assert float(oa.state[pa[0]]["step"]) == 6.0 and not oa.state[pa[-1]]
     sd = oa.state_dict()
-    ob2 = torch.optim.Adam(pb, 1e-3, (.5, .9))
+    ob2 = torch.optim.Adam(pb + [late_b], 1e-3, (.5, .9))
     ob2.load_state_dict(sd)                           # torch's Adam accepts the layout
-    oa2 = FusedAdam(pa, torch.tensor(1e-3, device=dev), (.5, .9))
+    oa2 = FusedAdam(pa + [late_a], torch.tensor(1e-3, device=dev), (.5, .9))
     import copy
     oa2.load_state_dict(copy.deepcopy(ob.state_dict()))   # and back (a copy: load_state_dict keeps same-device tensors by reference); the loaded step counter is adopted
     for a, b in zip(pa[:-1], pb[:-1]):
@@ -491,8 +500,8 @@ def test_fused_adam_kernel_matches_torch_adam(dev):
     ob.param_groups[0]["lr"] = 1e-3
     oa2.param_groups[0]["lr"] = 1e-3                  # (load_state_dict brought torch's float learning rate along: the float path)
     oa2.step(); ob.step()
-    assert float(oa2.state[pa[0]]["step"]) == 7.0
-    for a, b in zip(pa[:-1], pb[:-1]):
+    assert float(oa2.state[pa[0]]["step"]) == 7.0 and float(oa2.state[late_a]["step"]) == 4.0
+    for a, b in zip(pa[:-1] + [late_a], pb[:-1] + [late_b]):
         assert rel_l2(a.detach(), b.detach()) < 2e-7
 
 
@@ -762,3 +771,34 @@ def test_loss_combine_is_the_aten_chain_bit_for_bit(dev):
         for i in range(n):
             assert torch.equal(scaled[i], logged_ref[i].detach()), i
             assert torch.equal(b[i].grad, a[i].grad), i
+
+
+def test_incoming_gradient_shared_with_another_node_is_not_accumulated_into_while_the_side_stream_reads_it(dev):
+    """``out = conv_a(h) + h``.  AddBackward hands ONE gradient tensor G to conv_a's backward (its dy) and to
+    the input buffer of h's producer; when conv_a's data gradient arrives there autograd adds it INTO G in place -- on the
+    compute stream, while conv_a's weight gradient may still be reading G on the side stream.  rave_amd.ops._OnSide keeps a
+    reference to an incoming dy until the branch is joined, which makes autograd add out of place.  The weight gradient of
+    conv_a with the side stream on must equal the one with it off, bit for bit, in every trial."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    gen = torch.Generator().manual_seed(8)
+    C_ = 192
+    g3 = ConvGeom(dilation=1, pad_left=1, pad_right=1, act=1, slope=0.2)
+    x = torch.randn(32, C_, 4096, generator=gen).to(dev)
+    w0 = (torch.randn(C_, C_, 3, generator=gen) * 0.05).to(dev)
+    wa = (torch.randn(C_, C_, 3, generator=gen) * 0.05).to(dev)
+    cot = torch.randn(32, C_, 4096, generator=gen).to(dev)
+
+    def run(side):
+        with _Env(RH_BWD_SIDE_STREAM=side):
+            p0, pa = w0.clone().requires_grad_(True), wa.clone().requires_grad_(True)
+            h = R.conv1d(x, p0, None, geom=g3)
+            out = (R.conv1d(h, pa, None, geom=g3) + h) * 1.25      # (the product makes G a fresh tensor nobody else holds)
+            out.backward(cot)
+            torch.cuda.synchronize()
+            return pa.grad.clone(), p0.grad.clone()
+
+    ref = run(0)
+    for _ in range(6):
+        got = run(1)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
