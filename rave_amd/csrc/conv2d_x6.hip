@@ -283,6 +283,9 @@ bool plan_c2x(C2X& p, C2XPlan* pl) {
         Cand c{tn, TR, nb, (TR - 1) * p.is_h + span_h + 1, (TQ - 1) * p.is_w + span_w + 1, 0, 0};
         c.P = nb * c.PH * c.PW;
         if (2 * c.P > 256 * 8) continue;
+        // (96-row tiles with the 64-column wave tile AND eight conversion tasks per thread do not fit 256 VGPRs -- that
+        // instance spilled 19 registers: such a patch takes the 32-column wave tile)
+        if (pl->tm == 3 && tn == 2 && 2 * c.P > 256 * 4) continue;
         c.lds = (size_t)(2 * 6 * BM + 6 * c.P) * 16;
         if (c.lds > 160 * 1024) continue;
         // two workgroups per CU (<= 80 KB each) matter more than the larger wave tile: with one, every barrier and the
@@ -346,7 +349,8 @@ int rh_conv2d_x6_launch(C2X& p, hipStream_t stream, const char* what, bool* used
 #define RH_C2X_CASE(TM_, TN_, NQ_) if (pl.tm == TM_ && pl.tn == TN_ && pl.nq == NQ_) c2x_go<TM_, TN_, NQ_>(p, pl, stream)
     RH_C2X_CASE(1, 2, 4); else RH_C2X_CASE(1, 2, 8); else RH_C2X_CASE(1, 1, 4); else RH_C2X_CASE(1, 1, 8);
     else RH_C2X_CASE(2, 2, 4); else RH_C2X_CASE(2, 2, 8); else RH_C2X_CASE(2, 1, 4); else RH_C2X_CASE(2, 1, 8);
-    else RH_C2X_CASE(3, 2, 4); else RH_C2X_CASE(3, 2, 8); else RH_C2X_CASE(3, 1, 4); else RH_C2X_CASE(3, 1, 8);
+    else RH_C2X_CASE(3, 2, 4); else RH_C2X_CASE(3, 1, 4); else RH_C2X_CASE(3, 1, 8);
+    else RH_REQUIRE(false, RH_ERR_UNSUPPORTED, "conv2d_x6: no kernel instance for tile plan (%d, %d, %d)", pl.tm, pl.tn, pl.nq);
 #undef RH_C2X_CASE
     if (int e = rh_check_launch(what)) return e;
     *used = true;

@@ -746,6 +746,7 @@ CONV2D_CASES = [
     (1, 16, 4, 11, 13, (2, 2), (4, 1), (1, 1), (0, 0), 1),      # stride > kernel: data-gradient phases without taps
     (2, 48, 40, 16, 300, (1, 1), (1, 1), (1, 1), (0, 0), 1),    # 1x1, three chunks, M = 40 -> 64 rows (TM = 2)
     (1, 64, 96, 20, 70, (3, 3), (1, 1), (1, 1), (1, 1), 1),     # 96 rows (TM = 3), four chunks
+    (1, 32, 96, 40, 70, (9, 3), (1, 1), (1, 4), (4, 4), 1),     # 96 rows + a wide patch: the 32-column wave tile (the 64-column one would spill)
     (1, 16, 16, 9, 1, (3, 1), (1, 1), (1, 1), (1, 0), 0),       # W = 1
 ]
 

@@ -64,7 +64,8 @@ def kernels(so_path=None):
     return out
 
 
-def scratch_kernels(patterns=("conv_x6_kernel", "wgrad_x6_kernel", "conv_igemm_dma_kernel", "wgrad_dma_kernel")):
+def scratch_kernels(patterns=("conv_x6_kernel", "wgrad_x6_kernel", "conv_igemm_dma_kernel", "wgrad_dma_kernel", "conv2d_x6_kernel",
+                             "wgrad2d_x6_kernel", "unit_x6_kernel", "conv2d_smallm_kernel", "conv2d_smallc_fwd_kernel")):
     return [k for k in kernels() if any(p in k["name"] for p in patterns) and (k["scratch"] or k["vgpr_spill"])]
 
 
