@@ -76,7 +76,10 @@ __device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* ds
 constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
 
 // AV: rows of R are 16-byte aligned -> the 8 samples of an R task are two 16-byte loads instead of eight 4-byte ones
-template <int TM, int WM, int WN, bool AV>
+// PART: the last column tile holds whole 32-column MFMA tiles past the end of the weight tensor -- their columns are
+// neither converted nor multiplied (a separate instantiation: the two uniform branches cost 14 VGPRs, which would take the
+// 64-row variants from three workgroups per CU to two)
+template <int TM, int WM, int WN, bool AV, bool PART>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 64 * WN;
@@ -121,7 +124,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         const int o = u % OCT, col = u / OCT;
         const int cc = (n0 + col) / p.T, t = (n0 + col) - cc * p.T;
         const bool ok = col < BN && n0 + col < p.N;
-        bdst[q] = col < BN ? (o >> 1) * B_UNITS + (o & 1) * B_GS + col : -1;
+        // columns past the end of the weight tensor convert nothing (their LDS slots keep whatever they hold: a column of
+        // the B operand only reaches its own output column, which is never stored)
+        bdst[q] = (PART ? ok : col < BN) ? (o >> 1) * B_UNITS + (o & 1) * B_GS + col : -1;
         bp0[q] = 8 * o * p.is + (ok ? p.off[t] : 0);                  // position of sample 0 relative to n * is
         boff[q] = ok ? (unsigned)((cc * p.s_row + bp0[q]) * 4) : kOOB;
     }
@@ -211,30 +216,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     const int bcol = g * B_GS + wn * 64 + j;
     // one LDS stage: the next step's samples wait in registers while the matrix cores work on this step's fragments
     // (the other workgroup of the CU runs its MFMAs while this one converts)
+    // How many of this wave's two 32-column tiles hold columns of the weight tensor at all (wave-uniform).  The 96-row layers
+    // run 96 x 256 workgroup tiles over N = 288 (k = 3) or 96 (k = 1) columns: the second tile of the former holds 32 live
+    // columns, the only tile of the latter 96 -- multiplying (and converting) the dead ones cost those layers 30-40 %.
+    const int live_tn = !PART ? 2 : (n0 + wn * 64 >= p.N ? 0 : (n0 + wn * 64 + 32 >= p.N ? 1 : 2));
+    const bool live1 = live_tn >= 1, live2 = live_tn == 2;            // scalar (wn, n0, N are): uniform branches below
     for (int s = 0; s < nst; ++s) {
         const bool more = s + 1 < nst;
         if (more) load(st0 + s + 1);
+        if (live1) {
 #pragma unroll
-        for (int kb = 0; kb < kKS; ++kb) {
-            const u32x4* al = a_st + kb * A_UNITS + arow;
-            const u32x4* bl = b_st + kb * B_UNITS + bcol;
-            bf16x8 bfr[2][3], afr[TM][3];
+            for (int kb = 0; kb < kKS; ++kb) {
+                const u32x4* al = a_st + kb * A_UNITS + arow;
+                const u32x4* bl = b_st + kb * B_UNITS + bcol;
+                bf16x8 bfr[2][3], afr[TM][3];
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < 2; ++tn)           // (a dead tile's slots hold stale data: read, never multiplied)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
-            constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
+                    for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn], 0, 0, 0);
+                    for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[0][SB[q]], acc[tm][0], 0, 0, 0);
+                        if (live2)
+                            acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[1][SB[q]], acc[tm][1], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();                 // every wave is done reading this step's fragments
         if (more) convert();
@@ -332,15 +345,22 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     return true;
 }
 
-template <int TM, int WM, bool AV>
-void go2(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
-    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM, AV>;
+template <int TM, int WM, bool AV, bool PART>
+void go3(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM, AV, PART>;
     constexpr size_t lds = kKS * (2 * (3 * 32 * TM * WM + 4) + 2 * (3 * 64 * (4 / WM) + 4)) * 16;
     static std::once_flag once;
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     rh_launch_main(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), lds, stream, p);
+}
+
+template <int TM, int WM, bool AV>
+void go2(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    constexpr int TPW = 2 * (4 / WM);                              // 32-column MFMA tiles per workgroup tile
+    if (rh_cdiv(p.N, 32) % TPW != 0) go3<TM, WM, AV, true>(p, pl, stream);
+    else go3<TM, WM, AV, false>(p, pl, stream);
 }
 
 template <int TM, int WM>
