@@ -303,7 +303,8 @@ def _dgrad(d, dy, wp, x, alpha, add, dx, s):
 
 # ---- weight-gradient branch on a side stream -----------------------------------------------------------------------------
 # In the backward pass the weight-gradient branch of a layer (wgrad kernel -> ordered reduction of its K-slice partials ->
-# weight-norm backward: one MFMA kernel with a bandwidth-bound store tail, then two small bandwidth-bound kernels) only
+# weight-norm backward: one MFMA kernel with a bandwidth-bound store tail, then two small bandwidth-bound kernels -- the
+# last of them collected over all layers of the branch into one launch at the join, _WN_PENDING below) only
 # feeds the optimizer, while the data-gradient chain is what the next layer waits for.  The branch (RH_BWD_SIDE_STREAM=0
 # disables) is enqueued on a second HIP stream: it forks after the kernels that produce its operands and is joined back (a) at the
 # end of the backward pass (autograd final callback) and (b) before a data-parallel bucket leaves (rave_amd.ddp).  Recorded
