@@ -266,6 +266,16 @@ int rh_act_bwd_f32(const float* dy, const float* y, int32_t act, float slope, in
 int64_t rh_act_bwd_bias_workspace_bytes(int32_t M);
 int rh_act_bwd_bias_f32(const float* dy, const float* y, int32_t act, float slope, int32_t B, int32_t M, int64_t plane, float* g,
                         float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream);
+/* AdaptiveInstanceNormalization in EVAL mode (rave/blocks.py:863-926; identity in training mode, :901-902).
+ * stats_update = `mean = x.mean(-1); std = x.std(-1); update(mean_buf, mean, n); update(std_buf, std, n)` (:876-879, :904-909,
+ * :915-920) on x (rows = batch * channels, l): per-row mean and unbiased standard deviation, then
+ * buf[:rows] += (stat - buf[:rows]) / (num_updates[0] + 1); num_updates is the module's device buffer (the caller
+ * increments it afterwards, as the reference does).  transfer = :887-895,
+ * y = (x - mean_x) / (std_x + 1e-5) * std_y + mean_y with per-row statistics. */
+int rh_adain_stats_update_f32(const float* x, int64_t rows, int32_t l, const float* num_updates, float* mean_buf,
+                              float* std_buf, rh_stream_t stream);
+int rh_adain_transfer_f32(const float* x, int64_t rows, int32_t l, const float* mean_x, const float* std_x,
+                          const float* mean_y, const float* std_y, float* y, rh_stream_t stream);
 /* nn.functional.avg_pool1d(x, 2) of MultiScaleDiscriminator (rave/discriminator.py:135). */
 int rh_avgpool2_fwd_f32(const float* x, int64_t rows, int32_t l_in, float* y, rh_stream_t stream);
 int rh_avgpool2_bwd_f32(const float* dy, int64_t rows, int32_t l_in, float* dx, rh_stream_t stream);

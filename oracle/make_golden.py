@@ -189,6 +189,56 @@ def golden_v3_gen_tiny(name="v3_gen_tiny.pt"):
     build_reference_rave("v2", capacity=4, latent_size=4, causal=False)   # reset the causal binding
 
 
+def golden_v3_validation_tiny(name="v3_val_tiny.pt"):
+    """RAVE.validation_step (rave/model.py:426-443) of the v3 configuration (Snake + AdaIN, causal, stereo) under
+    ``model.eval()``, where AdaptiveInstanceNormalization leaves its training-mode identity (rave/blocks.py:898-926): five
+    calls walk every branch -- default buffers (identity), two calls with ``learn_y`` set (running target statistics,
+    another batch size), one with ``learn_x`` set (source statistics + transfer), one with both cleared (transfer only).
+    Stored per call: the returned cat([x, y], -1), the latent mean, the validation distance; and the buffers left behind."""
+    cap, lat, n_signal = 6, 8, 8192
+    torch.manual_seed(0)
+    m = build_reference_rave("v3", n_channels=2, capacity=cap, latent_size=lat, causal=True)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("alpha"):
+                p_.copy_(0.5 + torch.rand_like(p_))
+    m.eval()
+    sd = {k: t(v) for k, v in m.state_dict().items() if k.startswith(("pqmf.", "encoder.", "decoder."))}
+    from rave import blocks
+    adains = [mod for mod in m.modules() if isinstance(mod, blocks.AdaptiveInstanceNormalization)]
+    assert len(adains) == 22
+    xs = [O.synthetic_batch(2, 2, n_signal, seed=5), O.synthetic_batch(3, 2, n_signal, seed=6),
+          O.synthetic_batch(2, 2, n_signal, seed=8)]
+    script = [(0, 0, 0), (1, 1, 0), (2, 1, 0), (0, 0, 1), (0, 0, 0)]        # (which x, learn_y, learn_x)
+    calls = []
+    for n, (xi, ly, lx) in enumerate(script):
+        for a in adains:
+            a.learn_y.fill_(ly)
+            a.learn_x.fill_(lx)
+        x = xs[xi]
+        seed = 100 + n
+        t_lat = n_signal // 16 // 128                     # 16 bands, ratios 4 * 4 * 4 * 2
+        torch.manual_seed(seed)
+        eps = torch.randn(x.shape[0], lat, t_lat)         # the draw reparametrize makes inside validation_step (its first
+        torch.manual_seed(seed)                           # and only consumer of the generator): randn_like(mean)
+        with torch.no_grad():
+            audio, mean = m.validation_step(x, 0)
+            y = audio[..., x.shape[-1]:]
+            assert mean.shape == eps.shape
+        buffers = [{k_: t(getattr(a, k_)) for k_ in ("mean_x", "std_x", "num_update_x", "mean_y", "std_y", "num_update_y")}
+                   for a in adains]
+        with torch.no_grad():
+            dist = sum(m.audio_distance(x, y).values())
+        calls.append(dict(x_index=xi, learn_y=ly, learn_x=lx, eps=eps, audio=t(audio), mean=t(mean), distance=t(dist),
+                          buffers_after=buffers))
+    names = [n_ for n_, mod in m.named_modules() if isinstance(mod, blocks.AdaptiveInstanceNormalization)]
+    out = dict(config=dict(capacity=cap, latent_size=lat, n_channels=2, causal=True, n_signal=n_signal),
+               state_dict=sd, xs=[t(x) for x in xs], calls=calls, adain_names=names)
+    torch.save(out, os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes;", [float(c["distance"]) for c in calls])
+    build_reference_rave("v2", capacity=4, latent_size=4, causal=False)   # reset the causal binding
+
+
 def golden_v2_small_tiny(name="v2_small_tiny.pt"):
     """configs/v2_small.gin (BASELINE configs[0] family): NoiseGeneratorV2 on the decoder.  Forward
     products of the reference with the uniform noise draw captured (first RNG draw of decoder.forward),
@@ -511,3 +561,4 @@ if __name__ == "__main__":
     golden_v3_step_tiny()
     golden_discrete_step_tiny()
     golden_v2_wide()
+    golden_v3_validation_tiny()

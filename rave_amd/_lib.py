@@ -145,6 +145,8 @@ def _load() -> C.CDLL:
         "rh_spectral_distance_workspace_bytes": ([], I64),
         "rh_spectral_distance_fwd_f32": ([P, P, I64, F, P, P, I64, P], C.c_int),
         "rh_spectral_distance_bwd_f32": ([P, P, P, P, I64, F, P, P, I32, P], C.c_int),
+        "rh_adain_stats_update_f32": ([P, I64, I32, P, P, P, P], C.c_int),
+        "rh_adain_transfer_f32": ([P, I64, I32, P, P, P, P, P, P], C.c_int),
         "rh_avgpool2_fwd_f32": ([P, I64, I32, P, P], C.c_int),
         "rh_avgpool2_bwd_f32": ([P, I64, I32, P, P], C.c_int),
     }

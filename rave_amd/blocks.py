@@ -125,8 +125,11 @@ def _act_of(m: nn.Module):
 
 
 class AdaptiveInstanceNormalization(nn.Module):
-    """rave/blocks.py:863-926: identity in training mode (:901-902); buffers kept for state_dict
-    compatibility.  Inference-time style transfer is out of the training hot path."""
+    """rave/blocks.py:863-926.  Identity in training mode (:901-902).  In eval mode the module keeps running statistics of the
+    maps it sees while ``learn_y`` / ``learn_x`` are set (per batch slot and channel: mean and unbiased std over time,
+    ``update`` :876-879) and, once both sides hold statistics, transfers x onto the target statistics (``transfer`` :887-895);
+    with the default buffers it returns x.  Statistics and the transfer run on the HIP kernels ``adain_stats_kernel`` /
+    ``adain_transfer_kernel`` (misc.hip); the flag buffers are read on the host, as the reference's ``if self.learn_y`` does."""
 
     def __init__(self, dim: int) -> None:
         super().__init__()
@@ -136,10 +139,37 @@ class AdaptiveInstanceNormalization(nn.Module):
             self.register_buffer(f"learn_{n}", torch.zeros(1))
             self.register_buffer(f"num_update_{n}", torch.zeros(1))
 
+    def update(self, target: torch.Tensor, source: torch.Tensor, num_updates: torch.Tensor) -> None:
+        """rave/blocks.py:876-879 (the reference's signature; ``forward`` uses the fused statistics kernel instead)."""
+        bs = source.shape[0]
+        target[:bs] += (source - target[:bs]) / (num_updates + 1)
+
+    def reset_x(self):
+        self.mean_x.zero_()
+        self.std_x.zero_().add_(1)
+        self.num_update_x.zero_()
+
+    def reset_y(self):
+        self.mean_y.zero_()
+        self.std_y.zero_().add_(1)
+        self.num_update_y.zero_()
+
+    def transfer(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.adain_transfer(x, self.mean_x, self.std_x, self.mean_y, self.std_y)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
             return x
-        raise NotImplementedError("rave_amd AdaIN: eval-mode statistics transfer is not on the training hot path")
+        if bool(self.learn_y):
+            ops.adain_stats_update(x, self.mean_y, self.std_y, self.num_update_y)
+            self.num_update_y += 1
+            return x
+        if bool(self.learn_x):
+            ops.adain_stats_update(x, self.mean_x, self.std_x, self.num_update_x)
+            self.num_update_x += 1
+        if bool(self.num_update_x) and bool(self.num_update_y):
+            x = self.transfer(x)
+        return x
 
 
 _DILATED_UNIT_ACTIVATION: Optional[Callable[[int], nn.Module]] = None

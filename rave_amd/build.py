@@ -84,7 +84,7 @@ def build(force: bool = False, verbose: bool = False, _variants: bool = True) ->
 # Measurement libraries (never loaded by the product path: rave_amd._lib takes them only through RAVE_HIP_LIB): the bf16x6
 # forward / data-gradient kernels with 3 or 4 partial products instead of 6 (common.hpp: RH_X6_PRODUCTS; bench.py's
 # forward_only_x3 / _x4 legs, tools/x6_products.py).  Only the sources that see the macro are recompiled.
-VARIANT_SOURCES = ["conv_x6_is1.hip", "conv_x6_is2.hip", "conv_x6_is4.hip", "unit_x6.hip", "conv_host.hip"]
+VARIANT_SOURCES = ["conv_x6_is1.hip", "conv_x6_is2.hip", "conv_x6_is4.hip", "unit_x6.hip", "conv_host.hip", "conv2d_x6.hip"]
 VAR = os.path.join(HERE, "_var")
 
 

@@ -770,3 +770,67 @@ extern "C" int rh_reparam_bwd_f32(const float* z, const float* eps, const float*
                        (float)(1.0 / ((double)batch * l)), dz);
     return rh_check_launch("reparam_bwd");
 }
+
+// ---- AdaptiveInstanceNormalization, eval mode (rave/blocks.py:863-926) -----------------------------------------------
+// Training mode is the identity; in eval mode the module keeps running per-(batch item, channel) statistics of the maps it
+// sees (learn_x / learn_y) and, once both sides hold statistics, maps x -> (x - mean_x) / (std_x + 1e-5) * std_y + mean_y.
+namespace {
+
+// One workgroup per (batch item, channel) row of x (rows, l): mean and the UNBIASED standard deviation of the row
+// (torch.std's default), two passes in a fixed order (deterministic), then the running update of rave/blocks.py:876-879,
+// target[:bs] += (source - target[:bs]) / (num_updates + 1), on the first `rows` entries of the two statistic buffers.
+__global__ __launch_bounds__(256) void adain_stats_kernel(const float* __restrict__ x, long l, const float* __restrict__ num_updates,
+                                                          float* __restrict__ mean_buf, float* __restrict__ std_buf) {
+    __shared__ float red[4];
+    const long r = blockIdx.x;
+    const float* xr = x + r * l;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < l; e += 256) s += xr[e];
+    const float mean = block_sum(s, red) / (float)l;
+    float q = 0.f;
+    for (long e = threadIdx.x; e < l; e += 256) { const float d = xr[e] - mean; q += d * d; }
+    const float var = block_sum(q, red) / (float)(l - 1);          // l == 1: 0 / 0 = NaN, as torch.std
+    if (threadIdx.x == 0) {
+        const float den = num_updates[0] + 1.f;
+        mean_buf[r] += (mean - mean_buf[r]) / den;
+        std_buf[r] += (sqrtf(var) - std_buf[r]) / den;
+    }
+}
+
+// y = (x - mean_x) / (std_x + 1e-5) * std_y + mean_y, statistics per row; every operation rounded on its own (the
+// reference is a chain of separate ATen operations: no fused multiply-add).
+__global__ __launch_bounds__(256) void adain_transfer_kernel(const float* __restrict__ x, long l, long total,
+                                                             const float* __restrict__ mean_x, const float* __restrict__ std_x,
+                                                             const float* __restrict__ mean_y, const float* __restrict__ std_y,
+                                                             float* __restrict__ y) {
+#pragma clang fp contract(off)
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long r = e / l;
+    const float n = (x[e] - mean_x[r]) / (std_x[r] + 1e-5f);
+    y[e] = n * std_y[r] + mean_y[r];
+}
+
+}  // namespace
+
+extern "C" int rh_adain_stats_update_f32(const float* x, int64_t rows, int32_t l, const float* num_updates, float* mean_buf,
+                                         float* std_buf, rh_stream_t stream) {
+    RH_REQUIRE(rows >= 0 && l > 0, RH_ERR_INVALID, "adain_stats_update: bad shape");
+    if (rows == 0) return RH_OK;
+    RH_REQUIRE(x && num_updates && mean_buf && std_buf, RH_ERR_INVALID, "adain_stats_update: null pointer");
+    RH_REQUIRE(rows < (1ll << 31), RH_ERR_UNSUPPORTED, "adain_stats_update: too many rows");
+    hipLaunchKernelGGL(adain_stats_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (long)l, num_updates,
+                       mean_buf, std_buf);
+    return rh_check_launch("adain_stats_update");
+}
+
+extern "C" int rh_adain_transfer_f32(const float* x, int64_t rows, int32_t l, const float* mean_x, const float* std_x,
+                                     const float* mean_y, const float* std_y, float* y, rh_stream_t stream) {
+    RH_REQUIRE(rows >= 0 && l > 0, RH_ERR_INVALID, "adain_transfer: bad shape");
+    const long total = (long)rows * l;
+    if (total == 0) return RH_OK;
+    RH_REQUIRE(x && mean_x && std_x && mean_y && std_y && y, RH_ERR_INVALID, "adain_transfer: null pointer");
+    hipLaunchKernelGGL(adain_transfer_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, (long)l, total,
+                       mean_x, std_x, mean_y, std_y, y);
+    return rh_check_launch("adain_transfer");
+}

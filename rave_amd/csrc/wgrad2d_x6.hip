@@ -318,6 +318,18 @@ bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
     return true;
 }
 
+// One instantiation -- and therefore one once_flag -- per kernel variant: every variant gets its own
+// MaxDynamicSharedMemorySize attribute (plans ask for up to 145 KB of dynamic LDS).
+template <int NQX, int SW>
+void w2x_go(const W2X& p, const W2XPlan& pl, hipStream_t stream) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2d_x6_kernel<NQX, SW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+    });
+    rh_launch_main(wgrad2d_x6_kernel<NQX, SW>, dim3((unsigned)pl.Z, (unsigned)pl.groups), dim3(kW2Threads), pl.lds, stream, p);
+}
+
 }  // namespace
 
 // bytes of partial-tile scratch the bf16x6 weight gradient wants; -1 = geometry not eligible
@@ -342,16 +354,9 @@ int rh_wgrad2d_x6_launch(const rh_conv2d_desc* d, const float* dy, const float* 
     if (pl.Z > 1 && (!ws || ws_bytes < need)) return RH_OK;
     p.G = dy; p.X = x;
     p.out = pl.Z > 1 ? (float*)ws : dw;
-    auto go = [&](auto kern) {
-        static std::once_flag once;
-        std::call_once(once, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        });
-        rh_launch_main(kern, dim3((unsigned)pl.Z, (unsigned)pl.groups), dim3(kW2Threads), pl.lds, stream, p);
-    };
-    if (d->sw == 2) go(wgrad2d_x6_kernel<3, 2>);
-    else if (pl.nqx == 3) go(wgrad2d_x6_kernel<3, 1>);
-    else go(wgrad2d_x6_kernel<6, 1>);
+    if (d->sw == 2) w2x_go<3, 2>(p, pl, stream);
+    else if (pl.nqx == 3) w2x_go<3, 1>(p, pl, stream);
+    else w2x_go<6, 1>(p, pl, stream);
     if (int e = rh_check_launch("wgrad2d_x6")) return e;
     *used = true;
     if (pl.Z > 1) return rh_reduce_partials_launch((const float*)ws, dw, nw, pl.Z, stream, "wgrad2d_x6_reduce");

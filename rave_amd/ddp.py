@@ -104,6 +104,7 @@ class GradReducer:
         self.bytes_reduced = 0
         self.bytes_overlapped = 0      # bytes whose all-reduce was issued from a hook, i.e. while backward still ran
         self.bytes_packed = 0          # bytes that had to be copied into a view (gradients not written in place)
+        self.side_issued = 0           # all-reduces issued from the weight-gradient side stream (see _launch)
         self._in_finish = False
 
     # ---- lifecycle of one step
@@ -144,11 +145,22 @@ class GradReducer:
         if missing:
             with torch.no_grad():
                 torch._foreach_zero_(missing)
-        if b.flat.is_cuda:        # gradients written by the weight-gradient side stream (rave_amd.ops._OnSide) must have landed
-            from . import ops
-            ops.join_side_streams()
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
+        side = None
+        if b.flat.is_cuda:
+            # Gradients of this bucket may still be in flight on the weight-gradient side stream (rave_amd.ops._OnSide; the
+            # collected weight-norm backward of the branch is enqueued there now).  The collective is issued FROM that stream,
+            # which first waits for the compute stream: it is ordered behind every writer of the bucket on both streams, and
+            # the compute stream -- the data-gradient chain the rest of backward waits for -- is not stalled at the bucket
+            # boundary.  Nothing in flight there (side stream off, bucket of torch-op gradients): issued from the compute stream.
+            from . import ops
+            side = ops.side_stream_for_collective(b.flat.device)
+        if side is not None:
+            with torch.cuda.stream(side):
+                b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
+            self.side_issued += 1
+        else:
+            b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         b.launched = True
         self.bytes_reduced += b.numel * 4
         if not self._in_finish:
@@ -198,15 +210,36 @@ class BufferSync:
     point-to-point, one large broadcast beats hundreds of small ones); integer buffers (``receptive_field``,
     BatchNorm's ``num_batches_tracked``) are broadcast one by one."""
 
-    def __init__(self, module: torch.nn.Module, src: int = 0, process_group=None, force: bool = False):
+    # Buffers that no training step writes: filter-bank coefficients, STFT windows, and AdaIN's statistics (the module is
+    # the identity in training mode, rave/blocks.py:901-902; its buffers only move in eval mode).  They are identical on every
+    # rank after broadcast_module() and stay so: not re-sent every step (round 4 broadcast all of them: 1.5 MB of PQMF /
+    # window constants and 22 x 4 AdaIN tensors per v3 step).
+    STATIC_OWNERS = ("CachedPQMF", "PQMF", "MultiScaleSTFT", "AdaptiveInstanceNormalization", "Spectrogram", "_Stft")
+
+    def __init__(self, module: torch.nn.Module, src: int = 0, process_group=None, force: bool = False,
+                 all_buffers: bool = False):
+        """``all_buffers=True``: torch DDP's exact ``broadcast_buffers`` behaviour (every buffer, every step)."""
         self.pg, self.src, self.force = process_group, src, force
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        bufs = [b for b in module.buffers() if b.numel() > 0]
+        bufs, self.skipped = [], []
+        seen = set()
+        for mod in module.modules():
+            static = (not all_buffers) and type(mod).__name__ in self.STATIC_OWNERS
+            for name, b in mod.named_buffers(recurse=False):
+                if b.numel() == 0 or id(b) in seen:
+                    continue
+                seen.add(id(b))
+                # (a static owner's own flags / counters are tiny and may be host-visible state: only its float tables stay)
+                if static and b.is_floating_point():
+                    self.skipped.append(b)
+                else:
+                    bufs.append(b)
         self.fbufs = [b for b in bufs if b.is_floating_point()]
         self.ibufs = [b for b in bufs if not b.is_floating_point()]
         self.flat: Optional[torch.Tensor] = None
         self.bytes_sent = 0
         self.bytes_per_sync = sum(b.numel() * b.element_size() for b in bufs)
+        self.bytes_static = sum(b.numel() * b.element_size() for b in self.skipped)
 
     def sync(self) -> None:
         """Call at the start of every step (before the forward pass)."""

@@ -4,7 +4,8 @@ On the GPU one STFT scale is: HIP framing kernel (centre + reflect pad + Hann) -
 hipFFT directly (rave_amd/fft.py) -> ONE fused HIP kernel for magnitude, linear + log distance and the three
 reductions; backward: fused gradient kernel emitting the operand of the C2R adjoint of rfft -> rocFFT C2R ->
 HIP framing adjoint (rave_amd.ops.stft_distance).  Only the FFT itself is library code.
-The CPU branch keeps the reference's torch formulation and is what the parity tests compare with.
+There is no CPU branch: the reference's torch formulation lives in oracle/rave_oracle.py (audio_distance_v1) and is what the
+parity tests compare with.
 """
 from __future__ import annotations
 
@@ -49,20 +50,15 @@ class MultiScaleSTFT(nn.Module):
             self.register_buffer(f"window_{s}", torch.hann_window(s), persistent=False)
 
     def complex_stfts(self, x):
+        """Complex spectrograms (rows, frames, bins): torch.stft's with the (frequency, frame) axes swapped."""
         x = x.reshape(-1, x.shape[-1])
-        if x.is_cuda:
-            # framing (centre + reflect pad + Hann window) in one HIP pass, FFT on rocFFT; the result is
-            # torch.stft's spectrogram with the (frequency, frame) axes swapped, which the distance ignores
-            from . import ops
-            return [torch.fft.rfft(ops.stft_frames(x, getattr(self, f"window_{s}"), s, s // 4), dim=-1)
-                    for s in self.scales]
-        return [torch.stft(x, s, s // 4, s, window=getattr(self, f"window_{s}"), center=True,
-                           pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
-                for s in self.scales]
+        # framing (centre + reflect pad + Hann window) in one HIP pass (raises on a CPU tensor), FFT on rocFFT
+        from . import ops
+        return [torch.fft.rfft(ops.stft_frames(x, getattr(self, f"window_{s}"), s, s // 4), dim=-1) for s in self.scales]
 
     def forward(self, x):
-        out = [y.abs() for y in self.complex_stfts(x)]
-        return [y.transpose(-1, -2) for y in out] if x.is_cuda else out
+        """Magnitudes in torch.stft's (rows, bins, frames) layout."""
+        return [y.abs().transpose(-1, -2) for y in self.complex_stfts(x)]
 
 
 class AudioDistanceV1(nn.Module):
@@ -74,21 +70,13 @@ class AudioDistanceV1(nn.Module):
         self.log_epsilon = log_epsilon
 
     def forward(self, x, y):
-        if x.is_cuda:
-            # STFT, magnitudes, both distances and their reductions inside one HIP kernel per scale (rh_stft_loss_*_f32)
-            from . import ops
-            ms = self.multiscale_stft
-            xr, yr = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
-            # all scales in ONE autograd node: the scale sum and the per-signal gradient accumulation happen inside
-            distance = ops.multiscale_stft_distance(xr, yr, [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales,
-                                                    float(self.log_epsilon))
-            return {"spectral_distance": distance}
-        stfts_x = self.multiscale_stft(x)
-        stfts_y = self.multiscale_stft(y)
-        distance = 0.
-        for a, b in zip(stfts_x, stfts_y):
-            loga = torch.log(a + self.log_epsilon)
-            logb = torch.log(b + self.log_epsilon)
-            distance = distance + mean_difference(a, b, norm="L2", relative=True) \
-                + mean_difference(loga, logb, norm="L1")
+        if not (x.is_cuda and y.is_cuda):
+            raise RuntimeError("rave_amd AudioDistanceV1: inputs must live on the GPU (the HIP path has no CPU fallback)")
+        # STFT, magnitudes, both distances and their reductions inside one HIP kernel per scale (rh_stft_loss_*_f32)
+        from . import ops
+        ms = self.multiscale_stft
+        xr, yr = x.reshape(-1, x.shape[-1]), y.reshape(-1, y.shape[-1])
+        # all scales in ONE autograd node: the scale sum and the per-signal gradient accumulation happen inside
+        distance = ops.multiscale_stft_distance(xr, yr, [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales,
+                                                float(self.log_epsilon))
         return {"spectral_distance": distance}

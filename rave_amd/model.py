@@ -222,6 +222,14 @@ class RAVE(nn.Module):
             total = part if total is None else total + part
         return total
 
+    @staticmethod
+    def _join_side() -> None:
+        """The weight-gradient side stream (rave_amd.ops._OnSide) is joined by a callback at the end of every backward pass;
+        joining again before the optimizer reads the gradients is a no-op then, and the safety net when a pass ended
+        without running its callbacks."""
+        from . import ops
+        ops.join_side_streams()
+
     def split_features(self, features):
         """rave/model.py:276-286."""
         feature_real, feature_fake = [], []
@@ -352,6 +360,7 @@ class RAVE(nn.Module):
             loss_dis.backward()
             if grad_sync is not None:
                 grad_sync(1)
+            self._join_side()
             dis_opt.step()
         else:
             gen_opt.zero_grad()
@@ -364,6 +373,7 @@ class RAVE(nn.Module):
             loss_gen_value.backward()
             if grad_sync is not None:
                 grad_sync(0)
+            self._join_side()
             gen_opt.step()
 
         self.release_weights()
@@ -373,6 +383,27 @@ class RAVE(nn.Module):
         self.logged = dict(loss_gen)
         self.logged["loss_dis"] = loss_dis
         return self.logged
+
+
+    # ---- rave/model.py:426-443
+    def validation_step(self, x, batch_idx, eps: Optional[torch.Tensor] = None):
+        """Returns (cat([x, y], -1), latent mean or None), as the reference; the validation distance is kept in
+        ``self.logged["validation"]`` (the reference logs it through the trainer).  ``eps`` injects the reparametrisation
+        draw (parity runs).  Lightning calls this under ``model.eval()``: AdaptiveInstanceNormalization sites then run
+        their statistics / transfer branch (blocks.AdaptiveInstanceNormalization)."""
+        if x.is_cuda:
+            self.prepare_weights(reuse=True)
+        z = self.encode(x)
+        if isinstance(self.encoder, blocks.VariationalEncoder):
+            mean = torch.split(z, z.shape[1] // 2, 1)[0]
+        else:
+            mean = None
+        z = self.encoder.reparametrize(z, eps)[0]
+        y = self.decode(z)
+        distance = self.audio_distance(x, y)
+        self.logged["validation"] = sum(distance.values())
+        self.release_weights()
+        return torch.cat([x, y], -1), mean
 
 
 class LinearLR:

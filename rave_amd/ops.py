@@ -355,12 +355,36 @@ def _flush_wn_pending(stream_ptr) -> None:
     L.check(L.lib.rh_weight_norm_bwd_batched_f32(arr, len(items), stream_ptr), "weight_norm_bwd_batched")
 
 
+def side_stream_for_collective(device):
+    """Data-parallel bucket leaving while the backward pass still runs (rave_amd.ddp.GradReducer._launch): returns the stream
+    the bucket's all-reduce must be ISSUED FROM so that it is ordered behind every gradient written so far -- the
+    weight-gradient side stream, after the collected weight-norm launch of the branch has been enqueued there and after it
+    has been made to wait for the calling (compute) stream -- or None when the branch has nothing in flight.  The compute
+    stream itself is NOT made to wait: the data-gradient chain keeps running while the branch finishes and the collective
+    starts (round 4 joined the branch into the compute stream at every bucket boundary)."""
+    pend = _SIDE_PENDING[0]
+    if pend is None:
+        return None
+    side = pend[1]
+    if _WN_PENDING:
+        with torch.cuda.stream(side):
+            _flush_wn_pending(L.stream())
+    side.wait_stream(torch.cuda.current_stream(device))
+    return side
+
+
+def _graph_task_id() -> int:
+    """Id of the autograd graph task (backward pass) this thread is executing, -1 outside one."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return int(f()) if f is not None else -1
+
+
 def join_side_streams() -> None:
     """The calling stream waits for everything enqueued on the weight-gradient side stream (after the collected
     weight-norm backward launches of that branch have been enqueued there)."""
     pend = _SIDE_PENDING[0]
     if pend is not None:
-        main, side = pend
+        main, side = pend[0], pend[1]
         if _WN_PENDING:
             with torch.cuda.stream(side):
                 _flush_wn_pending(L.stream())
@@ -442,8 +466,16 @@ class _OnSide:
         import os
         if os.environ.get("RH_SIDE_HOLD", "1") != "0":      # (0: the unprotected form, for the test that shows the race)
             _SIDE_HOLD.extend(self.hold)
-        if _SIDE_PENDING[0] is None:
-            _SIDE_PENDING[0] = (self.main, self.side)
+        # The join is queued once per BACKWARD PASS (graph task).  A pass that raised after queueing never ran its callback
+        # and left the pending state behind: a pending entry of ANOTHER pass is joined here and now, so that its
+        # collected weight-norm launch still runs and a later pass queues its own join.
+        task = _graph_task_id()
+        pend = _SIDE_PENDING[0]
+        if pend is not None and pend[2] != task:
+            join_side_streams()
+            pend = None
+        if pend is None:
+            _SIDE_PENDING[0] = (self.main, self.side, task)
             try:        # end of this backward pass: the compute stream waits for the branch
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
             except RuntimeError:
@@ -1015,6 +1047,47 @@ class _SnakeFn(torch.autograd.Function):
 
 def snake(x: Tensor, alpha: Tensor) -> Tensor:
     return _SnakeFn.apply(x, alpha)
+
+
+class _AdainTransferFn(torch.autograd.Function):
+    """(x - mean_x) / (std_x + 1e-5) * std_y + mean_y with per-(batch item, channel) statistics (rave/blocks.py:887-895).
+    Backward = the same kernel on dy with zero means (d/dx = std_y / (std_x + 1e-5); the statistics are buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, mean_x, std_x, mean_y, std_y):
+        x = _chk(x, "x")
+        b, c, l = x.shape
+        stats = [_chk(t[:b], "statistics") for t in (mean_x, std_x, mean_y, std_y)]
+        y = torch.empty_like(x)
+        L.check(L.lib.rh_adain_transfer_f32(L.ptr(x), b * c, l, *[L.ptr(t) for t in stats], L.ptr(y), L.stream()), "adain_transfer")
+        ctx.save_for_backward(stats[1], stats[3])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        std_x, std_y = ctx.saved_tensors
+        dy = _chk(dy, "dy")
+        b, c, l = dy.shape
+        zero = torch.zeros_like(std_x)
+        dx = torch.empty_like(dy)
+        L.check(L.lib.rh_adain_transfer_f32(L.ptr(dy), b * c, l, L.ptr(zero), L.ptr(std_x), L.ptr(zero), L.ptr(std_y), L.ptr(dx),
+                                            L.stream()), "adain_transfer_bwd")
+        return dx, None, None, None, None
+
+
+def adain_transfer(x: Tensor, mean_x: Tensor, std_x: Tensor, mean_y: Tensor, std_y: Tensor) -> Tensor:
+    return _AdainTransferFn.apply(x, mean_x, std_x, mean_y, std_y)
+
+
+def adain_stats_update(x: Tensor, mean_buf: Tensor, std_buf: Tensor, num_updates: Tensor) -> None:
+    """mean_buf[:B] / std_buf[:B] <- running average with the per-row mean / unbiased std of x (B, C, L), in place
+    (rave/blocks.py:876-879, 904-909); ``num_updates`` is the module's 1-element device buffer."""
+    x = _chk(x.detach(), "x")
+    b, c, l = x.shape
+    if b > mean_buf.shape[0] or mean_buf.shape[1] != c or not (mean_buf.is_contiguous() and std_buf.is_contiguous()):
+        raise ValueError(f"adain statistics buffers {tuple(mean_buf.shape)} do not cover a batch of {b} x {c} channels")
+    L.check(L.lib.rh_adain_stats_update_f32(L.ptr(x), b * c, l, L.ptr(num_updates), L.ptr(mean_buf), L.ptr(std_buf), L.stream()),
+            "adain_stats_update")
 
 
 class _StftFrameFn(torch.autograd.Function):

@@ -34,6 +34,17 @@ class FusedAdam(torch.optim.Optimizer):
             gs["lr_dev"] = None
         return gs
 
+    def load_state_dict(self, state_dict) -> None:
+        """torch's loader, then every step counter as ONE f32 device scalar (a state_dict written by torch's Adam carries CPU /
+        1-element / integer counters): nothing is left to convert inside ``step``, where a conversion would be a host
+        synchronisation (illegal while a hipGraph records)."""
+        super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            t = st.get("step")
+            if t is not None and not (torch.is_tensor(t) and t.device == p.device and t.dtype == torch.float32 and t.dim() == 0):
+                st["step"] = torch.as_tensor(float(t), dtype=torch.float32).to(p.device).reshape(())
+        self._tables.clear()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -56,13 +67,20 @@ class FusedAdam(torch.optim.Optimizer):
                 if not g.is_contiguous():
                     g = p.grad = g.contiguous()
                 st = self.state[p]
+                capturing = torch.cuda.is_current_stream_capturing()
                 if not st:
+                    if capturing:       # state created here would be re-zeroed by every replay of the recorded step
+                        raise RuntimeError("rave_amd FusedAdam: a parameter received its first gradient inside a hipGraph capture; "
+                                           "run one eager step (or GraphedTrainingStep's warm-up) first")
                     st["step"] = torch.zeros((), device=p.device, dtype=torch.float32)     # per parameter, as torch's Adam
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 else:
                     t = st["step"]
                     if not (torch.is_tensor(t) and t.device == p.device and t.dtype == torch.float32 and t.dim() == 0):
+                        if capturing:   # float(t) is a host synchronisation: illegal while recording
+                            raise RuntimeError("rave_amd FusedAdam: step counters of a loaded state_dict must be normalised by one "
+                                               "eager step (or load_state_dict of this class) before a hipGraph capture")
                         # after load_state_dict of a foreign layout (CPU / int / 1-element counters): one device scalar
                         st["step"] = torch.as_tensor(float(t), dtype=torch.float32).to(p.device).reshape(())
                 live.append((p, g, st["exp_avg"], st["exp_avg_sq"], st["step"]))
@@ -85,7 +103,7 @@ class FusedAdam(torch.optim.Optimizer):
                     arr[i].step = t.data_ptr()
                 tab = self._tables[gi] = (key, arr)
             if gs["aux"] is None or gs["aux"].numel() < 2 * len(live):
-                if torch.cuda.is_current_stream_capturing() and gs["aux"] is not None:
+                if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("rave_amd FusedAdam: more parameters received gradients inside a hipGraph capture than in "
                                        "the eager steps before it")
                 gs["aux"] = torch.zeros(2 * len(live), device=gs["dev"], dtype=torch.float32)

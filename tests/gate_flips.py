@@ -94,6 +94,23 @@ def flips_downstream_by_param(log, flips):
     return out
 
 
+def flip_allowance_by_param(log, flips):
+    """{parameter name: the relative gradient change the flips DOWNSTREAM of it account for}.  One flipped LeakyReLU(0.2) gate
+    in a map of n elements changes that element's derivative by 0.8 of its value, i.e. the gradient flowing back through
+    the map by ~ 0.8 / sqrt(n) relative L2 (measured: one flip in the golden CAPACITY-96 fixture moved the two tensors upstream
+    of it by 2.0e-4 and 2.6e-3); independent flips add in quadrature:
+    allowance = 0.8 * sqrt(sum over later launches of flips_j / numel_j).  0 for a tensor with no flipped gate downstream."""
+    term = [0.0] * (len(log) + 1)
+    for i in range(len(log) - 1, -1, -1):
+        x = log[i][1]
+        term[i] = term[i + 1] + (flips[i] / x.numel() if (x is not None and flips[i]) else 0.0)
+    out = {}
+    for i, (names, _) in enumerate(log):
+        for k in names:
+            out[k] = 0.8 * term[i + 1] ** 0.5
+    return out
+
+
 def params_upstream_of(t: torch.Tensor):
     """ids of the leaf tensors (parameters) the autograd graph of ``t`` reaches."""
     seen, out, stack = set(), set(), [t.grad_fn]

@@ -300,3 +300,29 @@ def test_world_size_8_partition_and_buckets(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         shard_batch(100, 0, 8)
+
+
+def test_buffer_sync_skips_buffers_no_training_step_writes():
+    """BufferSync re-sends only state that can change between steps: RVQ codebooks and flags travel; PQMF
+    filter banks, STFT windows and AdaIN's statistics (identity in training mode, rave/blocks.py:901-902) are identical on
+    every rank after broadcast_module() and stay behind.  ``all_buffers=True`` = torch DDP's broadcast_buffers."""
+    from rave_amd import model as M
+    from rave_amd.ddp import BufferSync
+    m = M.build_v3(capacity=4, latent_size=4)
+    s = BufferSync(m)
+    names = {id(b): k for k, b in m.named_buffers()}
+    sent = {names[id(b)] for b in s.fbufs + s.ibufs}
+    skipped = {names[id(b)] for b in s.skipped}
+    assert "pqmf.hk" in skipped and "pqmf.h" in skipped
+    assert any(k.endswith(".mean_x") for k in skipped) and any(k.endswith("window") or ".window_" in k for k in skipped)
+    assert "receptive_field" in sent and "encoder.warmed_up" in sent
+    assert not any(k.endswith((".mean_x", ".std_y")) or k.startswith("pqmf.") for k in sent)
+    full = BufferSync(m, all_buffers=True)
+    assert not full.skipped and full.bytes_per_sync == s.bytes_per_sync + s.bytes_static
+    d = M.build_discrete(capacity=4, latent_size=4, num_quantizers=2, codebook_size=8, noise_augmentation=2)
+    sd_ = BufferSync(d)
+    dn = {id(b): k for k, b in d.named_buffers()}
+    sent_d = {dn[id(b)] for b in sd_.fbufs + sd_.ibufs}
+    for k in ("encoder.rvq.layers.0._codebook.embed", "encoder.rvq.layers.1._codebook.cluster_size",
+              "encoder.rvq.layers.0._codebook.inited", "encoder.enabled"):
+        assert k in sent_d, k

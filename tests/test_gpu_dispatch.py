@@ -400,9 +400,7 @@ def test_multiscale_stft_distance_node_equals_the_per_scale_nodes(dev):
         gx2, gy2 = torch.autograd.grad(d2, (x, y))
         assert abs(float(d1) - float(d2)) <= 2e-6 * abs(float(d2))
         assert rel_l2(gx1, gx2) < 1e-6 and rel_l2(gy1, gy2) < 1e-6
-        from functools import partial
-        ref = LS.AudioDistanceV1(partial(LS.MultiScaleSTFT, scales=scales, magnitude=True), 1e-7)
-        d3 = ref(x.detach().cpu().unsqueeze(1), y.detach().cpu().unsqueeze(1))["spectral_distance"]
+        d3 = O.audio_distance_v1(x.detach().cpu().unsqueeze(1), y.detach().cpu().unsqueeze(1), O.v2_config(stft_scales=tuple(scales)))
         assert abs(float(d1) - float(d3)) <= 2e-5 * abs(float(d3))
         d4 = R.multiscale_stft_distance(x, y, wins, scales, 1e-7)        # default: transform inside the kernel
         assert abs(float(d4) - float(d3)) <= 2e-5 * abs(float(d3))

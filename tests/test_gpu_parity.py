@@ -446,10 +446,9 @@ def test_fused_spectral_distance_vs_torch(dev):
     x = O.synthetic_batch(3, 1, 16384, seed=4)
     y = (x + 0.05 * torch.randn(x.shape, generator=g)).clamp(-1, 1)
     for eps, check_grad in ((1e-7, False), (1e-2, True)):
-        mk = lambda: losses.AudioDistanceV1(partial(losses.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128]), eps)
-        ref_mod, gpu_mod = mk(), mk().to(dev)
+        gpu_mod = losses.AudioDistanceV1(partial(losses.MultiScaleSTFT, scales=[2048, 1024, 512, 256, 128]), eps).to(dev)
         xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
-        d_ref = ref_mod(xr, yr)["spectral_distance"]
+        d_ref = O.audio_distance_v1(xr, yr, O.v2_config(log_epsilon=eps))
         xg, yg = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
         d = gpu_mod(xg, yg)["spectral_distance"]
         assert abs(float(d) - float(d_ref)) <= 2e-5 * abs(float(d_ref))
@@ -1137,28 +1136,74 @@ def test_discrete_spectral_training_step_golden(golden_dir, dev, tag, idx):
 # bf16x6 kernels (conv_x6_kernel.inc: every tile shape, split-K, batch folding at the short stages, the
 # phase-interleaved strided form, the per-phase transposed form) and the weight gradients at C = 768 / 1536 are
 # compared with the CPU oracle INSIDE the module graph, forward and backward.
-def _full_width_grads(dev, batch, x6_mode, reparam_fused="0", gates=None):
+DISCRETE_CODEBOOK_SEED = 431      # of 1500 seeds the one whose closest runner-up code is farthest behind (tools/debug/rvq_margin_search.py)
+
+
+def _full_width_fixture(kind, batch):
+    """(cfg, state_dict, x, eps / noise, builder kwargs) of the full-width fixtures: "v2" = BASELINE configs[1], "v3" =
+    configs[4]'s generator side (v3.gin:3-13 + causal.gin:5: stereo, causal, Snake with non-trivial alphas, AdaIN), "discrete"
+    = configs[3]'s (discrete.gin:13-49: RATIOS [4,4,2,2], EncoderV2(n_out=1), 16 x 1024-code RVQ ENABLED, 128 noise channels)."""
+    gen = torch.Generator().manual_seed(7)
+    if kind == "v2":
+        cfg = O.v2_config()
+        sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+        x = O.synthetic_batch(batch, 1, 65536)
+        eps = torch.randn(batch, 128, 32, generator=gen)
+    elif kind == "v3":
+        cfg = O.v3_config()
+        sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+        ga = torch.Generator().manual_seed(11)
+        for k in sorted(sd):
+            if k.endswith(".alpha"):
+                sd[k] = 0.5 + torch.rand(sd[k].shape, generator=ga)
+        x = O.synthetic_batch(batch, 2, 65536)
+        eps = torch.randn(batch, 128, 32, generator=gen)
+    elif kind == "discrete":
+        cfg = O.discrete_config()
+        sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
+        x = O.synthetic_batch(batch, 1, 65536)
+        with torch.no_grad():       # codes at the scale of the vectors they quantise (what the reference's k-means init gives)
+            zp = O.encoder_v2(O.pqmf_encode(x, sd["pqmf.forward_conv.weight"]), sd, cfg)
+        sd.update(O.seeded_codebooks(cfg, DISCRETE_CODEBOOK_SEED, scale=float(zp.pow(2).mean().sqrt())))
+        eps = torch.randn(batch, 128, 64, generator=gen)
+    else:
+        raise ValueError(kind)
+    return cfg, sd, x, eps, gen
+
+
+def _full_width_grads(dev, batch, x6_mode, reparam_fused="0", gates=None, kind="v2"):
     """``gates``: a dict that receives the named gate log of the HIP run and the fp64 oracle's LeakyReLU masks."""
     import os
     from rave_amd import model as M
-    cfg = O.v2_config()
-    sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
-    x = O.synthetic_batch(batch, 1, 65536)
-    gen = torch.Generator().manual_seed(7)
-    eps = torch.randn(batch, 128, 32, generator=gen)
+    cfg, sd, x, eps, gen = _full_width_fixture(kind, batch)
+    nch = cfg.n_channels
     # cotangents at the hot-path outputs, of the size class the loss produces there
-    cy_raw = torch.randn(batch, 1, 65536, generator=gen) * 1e-3
-    cy_mb = torch.randn(batch, 16, 4096, generator=gen) * 1e-3
+    cy_raw = torch.randn(batch, nch, 65536, generator=gen) * 1e-3
+    cy_mb = torch.randn(batch, 16 * nch, 4096, generator=gen) * 1e-3
+
+    def oracle_forward(xx, sdd, ee, margins=None):
+        if kind == "discrete":
+            # (a private copy of the buffers: the EMA update must start from the same codebooks in every evaluation)
+            return O.discrete_forward(xx, sdd, cfg, ee, training=True, margins=margins)
+        return O.rave_forward(xx, sdd, cfg, ee)
+
+    def leaf(k, v):
+        return v.is_floating_point() and k.startswith(("encoder.encoder.", "decoder.")) and (
+            k.endswith((".weight_v", ".weight_g", ".alpha", ".weight", ".bias")))
     # --- CPU oracle, fp32 (the reference's arithmetic) and fp64 (the yardstick for ill-conditioned gradients)
-    sdr = {k: (v.clone().requires_grad_(v.is_floating_point() and not k.startswith("pqmf."))) for k, v in sd.items()}
-    out = O.rave_forward(x, sdr, cfg, eps)
+    sdr = {k: v.clone().requires_grad_(leaf(k, v)) for k, v in sd.items()}
+    margins = [] if kind == "discrete" else None
+    out = oracle_forward(x, sdr, eps, margins)
     torch.autograd.backward([out["y_raw"], out["y_mb"], out["reg"]], [cy_raw, cy_mb, torch.ones(())])
-    sd64 = {k: (v.double().requires_grad_(not k.startswith("pqmf.")) if v.is_floating_point() else v) for k, v in sd.items()}
+    if margins is not None:
+        out["margins"] = torch.stack(margins, 1)
+    sd64 = {k: (v.double().requires_grad_(leaf(k, v)) if v.is_floating_point() else v) for k, v in sd.items()}
     from gate_flips import OracleGates, name_gate_log
     with OracleGates() as og:
-        out64 = O.rave_forward(x.double(), sd64, cfg, eps.double())
+        out64 = oracle_forward(x.double(), sd64, eps.double())
     torch.autograd.backward([out64["y_raw"], out64["y_mb"], out64["reg"]],
                             [cy_raw.double(), cy_mb.double(), torch.ones((), dtype=torch.float64)])
+    out["indices64"] = out64.get("indices")
     for k, v in sdr.items():
         v.grad64 = sd64[k].grad if torch.is_tensor(sd64[k]) and sd64[k].is_floating_point() else None
     # --- HIP path
@@ -1168,19 +1213,33 @@ def _full_width_grads(dev, batch, x6_mode, reparam_fused="0", gates=None):
     os.environ["RH_REPARAM_FUSED"] = reparam_fused
     try:
         from rave_amd import ops as R
-        m = M.build_v2()
-        m.load_state_dict(sd, strict=False)
+        m = {"v2": M.build_v2, "v3": M.build_v3, "discrete": M.build_discrete}[kind]()
+        res = m.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys[:5]
+        assert all(k.startswith("discriminator.") or k in ("receptive_field", "encoder.warmed_up") for k in res.missing_keys), \
+            [k for k in res.missing_keys if not k.startswith("discriminator.")][:5]
         m = m.to(dev).train()
         m.prepare_weights()
+        got = {}
+        if kind == "discrete":
+            assert int(m.encoder.enabled) == 1
+            rvq_forward = m.encoder.rvq.forward
+
+            def spy(z):
+                r = rvq_forward(z)
+                got["indices"] = r[2]
+                return r
+            m.encoder.rvq.forward = spy
         if gates is not None:
             R.gate_log_begin()
         zp, x_mb = m.encode(x.to(dev), return_mb=True)
-        z, reg = m.encoder.reparametrize(zp, eps.to(dev))
+        z, reg = m.encoder.reparametrize(zp, eps.to(dev))[:2]
         y_mb = m.decoder(z)
         if gates is not None:
             gates["log"] = name_gate_log(R.gate_log_end(), m)      # (the decoder runs again below: same gates, logged once)
             gates["oracle64"] = og.masks
-        y_raw = m.decode(z)
+        y_raw = m.decode(z)[..., :65536]
+        y_mb = y_mb[..., :4096]
         torch.autograd.backward([y_raw, y_mb, reg], [cy_raw.to(dev), cy_mb.to(dev), torch.ones((), device=dev)])
         m.release_weights()
         torch.cuda.synchronize()
@@ -1190,7 +1249,8 @@ def _full_width_grads(dev, batch, x6_mode, reparam_fused="0", gates=None):
                 os.environ.pop(key, None)
             else:
                 os.environ[key] = val
-    return m, sdr, out, dict(x_mb=x_mb, z_params=zp, y_mb=y_mb, y_raw=y_raw)
+    got.update(x_mb=x_mb, z_params=zp, z=z, reg=reg, y_mb=y_mb, y_raw=y_raw)
+    return m, sdr, out, got
 
 
 @pytest.mark.parametrize("x6_mode", ["1", "0"])
@@ -1257,6 +1317,131 @@ def test_v2_full_width_with_the_fused_reparametrisation_gate_flips_counted(dev):
     assert sum(flips) <= 1e-4 * n_gates and worst_mag < 1e-3
     for k, err, ref_err, d in outside:
         assert d >= 1, (k, err, ref_err, "outside the tight bound without a flipped gate downstream")
+
+
+@pytest.mark.parametrize("x6_mode", ["1", "0"])
+def test_v3_full_size_forward_backward_vs_oracle(dev, x6_mode):
+    """BASELINE configs[4]'s generator path at its benchmarked geometry (rave/configs/v3.gin:3-13 + causal.gin:5): CAPACITY 96,
+    65 536 samples, STEREO (2-channel PQMF fold, 32-band stem, 64-channel head), CAUSAL pads at C = 96 ... 1536, Snake with
+    non-trivial learnable alphas at every activation site, AdaIN sites (identity: training mode), batch 2 -- forward and
+    backward of PQMF -> EncoderV2 -> reparametrize (the default fused kernels) -> GeneratorV2 -> PQMF^-1 against the CPU oracle:
+    outputs <= 1e-4, all 166 generator-side parameter gradients (112 weight-norm tensors + 54 Snake alphas).  Snake is smooth:
+    there is no gate to flip, so the tight bounds hold for every tensor.  Both kernel modes."""
+    m, sdr, ref, got = _full_width_grads(dev, 2, x6_mode, reparam_fused="1", kind="v3")
+    assert got["x_mb"].shape == (2, 32, 4096) and got["z_params"].shape == (2, 256, 32) and got["y_raw"].shape == (2, 2, 65536)
+    assert rel_l2(got["x_mb"], ref["x_mb"]) < TOL_OP
+    for k in ("z_params", "z", "y_mb", "y_raw"):
+        assert rel_l2(got[k], ref[k]) < TOL_E2E, (k, rel_l2(got[k], ref[k]))
+    assert abs(float(got["reg"]) - float(ref["reg"])) <= 1e-4 * abs(float(ref["reg"]))
+    named = dict(m.named_parameters())
+    checked, worst, alphas = 0, 0.0, 0
+    for k, v in sdr.items():
+        if not v.requires_grad:
+            continue
+        assert v.grad is not None and named[k].grad is not None, k
+        ref_err = rel_l2(v.grad, v.grad64)
+        err = rel_l2(named[k].grad, v.grad64)
+        worst = max(worst, err)
+        tol = 1e-3 if k.endswith("weight_g") else 2e-4
+        assert err < max(tol, 3.0 * ref_err), (k, err, ref_err)
+        checked += 1
+        alphas += k.endswith(".alpha")
+    print(f"v3 full size (RH_CONV_X6={x6_mode}): worst gradient rel-L2 vs fp64 {worst:.2e} over {checked} tensors")
+    assert checked == 166 and alphas == 54, (checked, alphas)
+
+
+@pytest.mark.parametrize("x6_mode", ["1", "0"])
+def test_discrete_full_size_forward_backward_vs_oracle(dev, x6_mode):
+    """BASELINE configs[3]'s generator path at its benchmarked geometry (rave/configs/discrete.gin:13-49): CAPACITY 96, 65 536
+    samples, RATIOS [4,4,2,2] (stride-2 third stage, latent length 64), EncoderV2(n_out=1), the 16 x 1024-code residual
+    quantiser ENABLED in training mode (rave/quantization.py:131-181, 283-300: nearest code, EMA codebook update, commitment
+    loss, straight-through gradient), 128 injected noise channels, 256-channel decoder input, batch 2.
+    * code INDICES: ``torch.equal`` with the oracle's (2 x 16 x 64 assignments; the fixture's codebook seed was chosen so that
+      the closest runner-up code is >= 1e-5 behind in relative distance, 10x the f32 noise of the distances -- asserted);
+    * outputs <= 1e-4, EMA-updated codebooks <= 2e-5, commitment loss <= 1e-4;
+    * all 112 generator-side gradients, LeakyReLU gate flips against the fp64 evaluation COUNTED: a gradient outside the tight
+      bound must lie upstream of a flipped gate (tests/gate_flips.py).  Both kernel modes."""
+    from gate_flips import chain_flips, flip_allowance_by_param, flips_downstream_by_param
+    g = {}
+    m, sdr, ref, got = _full_width_grads(dev, 2, x6_mode, gates=g, kind="discrete")
+    assert float(ref["margins"].min()) >= 1e-5, float(ref["margins"].min())
+    assert torch.equal(ref["indices"], ref["indices64"])
+    assert got["indices"].shape == (2, 16, 64) and got["z"].shape == (2, 256, 64)
+    same = torch.equal(got["indices"].cpu().long(), ref["indices"].long())
+    if not same:
+        bad = (got["indices"].cpu().long() != ref["indices"].long())
+        raise AssertionError(f"{int(bad.sum())} code indices differ; oracle margins there: {ref['margins'][bad][:8].tolist()}")
+    assert rel_l2(got["x_mb"], ref["x_mb"]) < TOL_OP
+    for k in ("z_params", "z", "y_mb", "y_raw"):
+        assert rel_l2(got[k], ref[k]) < TOL_E2E, (k, rel_l2(got[k], ref[k]))
+    assert abs(float(got["reg"]) - float(ref["reg"])) <= 1e-4 * abs(float(ref["reg"]))
+    msd = m.state_dict()
+    for k, want in ref["codebooks"].items():
+        assert rel_l2(msd[k].float().cpu(), want.float()) < 2e-5, k
+    flips, n_gates, worst_mag = chain_flips(g["log"], g["oracle64"])
+    down = flips_downstream_by_param(g["log"], flips)
+    allow = flip_allowance_by_param(g["log"], flips)
+    named = dict(m.named_parameters())
+    outside, checked = [], 0
+    for k, v in sdr.items():
+        if not v.requires_grad:
+            continue
+        assert v.grad is not None and named[k].grad is not None, k
+        ref_err = rel_l2(v.grad, v.grad64)
+        err = rel_l2(named[k].grad, v.grad64)
+        tol = 1e-3 if k.endswith("weight_g") else 2e-4
+        if err >= max(tol, 3.0 * ref_err):
+            outside.append((k, err, ref_err, down[k]))
+        assert err < min(max(tol, 3.0 * ref_err) + 3.0 * allow[k], 5e-3), (k, err, ref_err, allow[k])
+        checked += 1
+    print(f"discrete full size (RH_CONV_X6={x6_mode}): gate flips vs fp64 {sum(flips)} of {n_gates}; outside the tight bound: "
+          f"{[(k, '%.1e' % e, d) for k, e, _, d in outside]}")
+    assert checked == 112, checked
+    assert sum(flips) <= 1e-4 * n_gates and worst_mag < 1e-3
+    for k, err, ref_err, d in outside:
+        assert d >= 1, (k, err, ref_err, "outside the tight bound without a flipped gate downstream")
+
+
+def test_v3_validation_step_adain_eval_golden(golden_dir, dev):
+    """RAVE.validation_step under model.eval() (rave/model.py:426-443) on the drop-ins, v3 configuration: every branch of
+    AdaptiveInstanceNormalization's eval forward (rave/blocks.py:898-926) -- identity on default buffers, running target
+    statistics (learn_y; two calls, another batch size), source statistics + transfer (learn_x), transfer only -- against
+    what the REFERENCE returned and left in its buffers (tests/golden/v3_val_tiny.pt, oracle/make_golden.py)."""
+    from rave_amd import blocks as B, model as M
+    g = _load(golden_dir, "v3_val_tiny.pt")
+    c = g["config"]
+    m = M.build_v3(n_channels=c["n_channels"], causal=c["causal"], capacity=c["capacity"], latent_size=c["latent_size"])
+    res = m.load_state_dict(g["state_dict"], strict=False)
+    assert not res.unexpected_keys and all(k.startswith("discriminator.") or k == "receptive_field" for k in res.missing_keys), res
+    m = m.to(dev).eval()
+    mods = dict(m.named_modules())
+    adains = [mods[n] for n in g["adain_names"]]
+    assert len(adains) == 22 and all(isinstance(a, B.AdaptiveInstanceNormalization) for a in adains)
+    for call in g["calls"]:
+        for a in adains:
+            a.learn_y.fill_(call["learn_y"])
+            a.learn_x.fill_(call["learn_x"])
+        x = g["xs"][call["x_index"]].to(dev)
+        with torch.no_grad():
+            audio, mean = m.validation_step(x, 0, eps=call["eps"].to(dev))
+        assert audio.shape == call["audio"].shape
+        assert rel_l2(audio, call["audio"]) < TOL_E2E, rel_l2(audio, call["audio"])
+        assert rel_l2(mean, call["mean"]) < TOL_E2E
+        want = float(call["distance"])
+        assert abs(float(m.logged["validation"]) - want) <= 2e-4 * abs(want)
+        for a, bufs in zip(adains, call["buffers_after"]):
+            for k, v in bufs.items():
+                have = getattr(a, k).cpu()
+                assert float((have - v).abs().max()) <= 1e-4 * max(1.0, float(v.abs().max())), k
+    # autograd through the transfer branch (rave.core.get_rave_receptive_field differentiates an eval-mode model)
+    a = adains[0]
+    xx = torch.randn(2, a.mean_x.shape[1], 64, device=dev, requires_grad=True)
+    a(xx).square().sum().backward()
+    xr = xx.detach().cpu().requires_grad_(True)
+    bs = 2
+    yr = (xr - a.mean_x[:bs].cpu()) / (a.std_x[:bs].cpu() + 1e-5) * a.std_y[:bs].cpu() + a.mean_y[:bs].cpu()
+    yr.square().sum().backward()
+    assert rel_l2(xx.grad, xr.grad) < TOL_OP
 
 
 def test_v2_full_width_x6_kernels_are_the_ones_that_ran(dev):

@@ -210,6 +210,32 @@ def test_v3_generator_side_golden(golden_dir):
         assert rel_l2(sd[k].grad, gref) < 2e-5, k
 
 
+def test_v3_validation_step_adain_eval_golden(golden_dir):
+    """RAVE.validation_step under model.eval() (rave/model.py:426-443) with every branch of AdaptiveInstanceNormalization's
+    eval forward (rave/blocks.py:898-926): identity on default buffers, running target statistics (learn_y, two batch sizes),
+    source statistics + transfer (learn_x), transfer only -- the oracle's adain_forward / validation_step vs the reference."""
+    g = _load(golden_dir, "v3_val_tiny.pt")
+    c = g["config"]
+    cfg = O.v3_config(capacity=c["capacity"], latent_size=c["latent_size"], eval_mode=True)
+    sd = {k: v.clone() for k, v in g["state_dict"].items()}
+    for call in g["calls"]:
+        for name in g["adain_names"]:
+            sd[name + ".learn_y"].fill_(call["learn_y"])
+            sd[name + ".learn_x"].fill_(call["learn_x"])
+        x = g["xs"][call["x_index"]]
+        with torch.no_grad():
+            audio, mean, dist = O.validation_step(x, sd, cfg, call["eps"])
+        assert audio.shape == call["audio"].shape and rel_l2(audio, call["audio"]) < TOL
+        assert rel_l2(mean, call["mean"]) < TOL
+        assert abs(float(dist) - float(call["distance"])) < 1e-4 * abs(float(call["distance"]))
+        for name, bufs in zip(g["adain_names"], call["buffers_after"]):
+            for k, v in bufs.items():
+                assert rel_l2(sd[f"{name}.{k}"], v) < TOL or float((sd[f"{name}.{k}"] - v).abs().max()) == 0.0, (name, k)
+    last = g["calls"][-1]["buffers_after"][0]
+    assert float(last["num_update_y"]) == 2 and float(last["num_update_x"]) == 1        # the script really walked the branches
+    assert float((last["std_x"][:2] - 1).abs().max()) > 1e-3
+
+
 def test_v2_small_noise_generator_golden(golden_dir):
     """configs/v2_small.gin: NoiseGeneratorV2 branch of GeneratorV2 (rave/blocks.py:243-292,696-711)."""
     g = _load(golden_dir, "v2_small_tiny.pt")
