@@ -10,6 +10,13 @@
 //     Y_k = (Z_k - conj Z_{n-k}) / 2i.  Stockham autosort, radix 8 (+ one radix 2 / 4 pass), n / 8 threads per transform
 //     holding 8 points each, 256 / (n / 8) transforms per workgroup side by side; LDS image padded by one slot per 8 so
 //     that the stride-8 stores of the first pass are conflict free; twiddles from a host-made table (f64 -> f32).
+//   * the two signals of a pair are EQUALISED first (round 5): y enters as s y with s = 2^(exponent of max |x| over the frame -
+//     exponent of max |y|), exact in floating point, and Y = Y' / s after the transform.  A transform's rounding error is
+//     ~ 1e-7 of the norm of its WHOLE input, so without this the quieter signal inherits the louder one's noise: at the start
+//     of training the decoder's output is ~ 50x below the target and d log(|Y| + 1e-7) turned that noise into a multiband
+//     gradient 60 % off the f64 value, where torch's separate f32 transforms are 0.3 % off
+//     (profiles/round5_stft_pair_equalisation.txt).  In the backward the gradient operand is scaled the other way
+//     (Wy / s, result x s), for the same reason: |Wy| ~ s |Wx|.
 //   * backward: the same transform again (the spectra are not stored), the gradient w.r.t. both magnitudes turned into
 //     the Hermitian-extended operand W = Wx + i Wy in place, the unnormalised inverse as swap(FFT(swap(W))) -> real part
 //     = d frame_x, imaginary part = d frame_y, window, overlap-add into an LDS image of the workgroup's span of the padded
@@ -21,6 +28,7 @@
 //   * sums[0] = sum (a-b)^2, sums[1] = sum a^2, sums[2] = sum |log(a+eps) - log(b+eps)| over all bins (a = |X|, b = |Y|):
 //     per-workgroup partials + ordered finalize, as spectral_partials_kernel; same gradient formula as spectral_bwd_kernel.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -194,6 +202,7 @@ struct StftP {
     float* dx;
     float* dy;
     int accumulate;
+    int equalise;            // 0: RH_STFT_EQUALISE=0 (diagnostics: the pair transform without the power-of-two equaliser)
 };
 
 __device__ __forceinline__ int reflect_at(int p, int t) { return p < 0 ? -p : (p >= t ? 2 * (t - 1) - p : p); }
@@ -223,6 +232,44 @@ __device__ __forceinline__ void load_frames(c32 (&v)[8], int t_len, const float*
     }
 }
 
+// Equaliser of a frame pair: s = 2^(e_x - e_y) from the largest |x| and |y| of the frame (all N samples: the TPF threads of
+// the transform; across waves through `fmx`, one slot per wave -- the barriers inside the transform that follows separate this
+// read from the next frame's write), 1 when either frame is all zero.  Every thread of the workgroup must call it.
+template <int TPF>
+__device__ __forceinline__ void frame_scale(const c32 (&vn)[8], c32* fmx, float& s, float& inv_s, int on) {
+    float mx = 0.f, my = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        mx = fmaxf(mx, fabsf(vn[r].x));
+        my = fmaxf(my, fabsf(vn[r].y));
+    }
+    constexpr int W = TPF < 64 ? TPF : 64;
+#pragma unroll
+    for (int o = W / 2; o >= 1; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        my = fmaxf(my, __shfl_xor(my, o, 64));
+    }
+    if (TPF > 64) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) fmx[wave] = mk(mx, my);
+        __syncthreads();
+        const int w0 = (threadIdx.x / TPF) * (TPF / 64);
+        mx = my = 0.f;
+#pragma unroll
+        for (int i = 0; i < TPF / 64; ++i) {
+            const c32 q = fmx[w0 + i];
+            mx = fmaxf(mx, q.x);
+            my = fmaxf(my, q.y);
+        }
+    }
+    int d = (mx > 0.f && my > 0.f) ? (int)(__float_as_uint(mx) >> 23) - (int)(__float_as_uint(my) >> 23) : 0;
+    d = d < -100 ? -100 : (d > 100 ? 100 : d);
+    if (!on) d = 0;
+    if (TPF >= 64) d = __builtin_amdgcn_readfirstlane(d);      // a whole wave works on one transform: the scale lives in an SGPR
+    s = __uint_as_float((unsigned)(127 + d) << 23);
+    inv_s = __uint_as_float((unsigned)(127 - d) << 23);
+}
+
 __device__ __forceinline__ float wg_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -239,6 +286,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const StftP p) {
     constexpr int TPF = F::TPF, G = F::G;
     __shared__ c32 zb[G * F::ZP];
     __shared__ float red[4];
+    __shared__ c32 fmx[4];
     const int tid = threadIdx.x;
     const int gi = tid / TPF, t = tid - gi * TPF;
     const int row = blockIdx.y;
@@ -254,9 +302,10 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const StftP p) {
     for (int r = 0; r < 8; ++r) wn[r] = p.win[t + r * TPF];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const float eps = p.eps;
+    float sc = 1.f, isc = 1.f;       // equaliser of the current frame pair and its inverse (frame_scale)
     auto bin = [&](c32 z1, c32 z2) {
         const float xr_ = 0.5f * (z1.x + z2.x), xi = 0.5f * (z1.y - z2.y);
-        const float yr_ = 0.5f * (z1.y + z2.y), yi = 0.5f * (z2.x - z1.x);
+        const float yr_ = (0.5f * isc) * (z1.y + z2.y), yi = (0.5f * isc) * (z2.x - z1.x);
         const float a2 = xr_ * xr_ + xi * xi, b2 = yr_ * yr_ + yi * yi;
         const float a = __builtin_amdgcn_sqrtf(a2), b = __builtin_amdgcn_sqrtf(b2);
         const float d = a - b;
@@ -270,8 +319,9 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const StftP p) {
     for (int fb = f0; fb < f1; fb += G) {
         const bool valid = fb + gi < f1;
         c32 v[8];
+        frame_scale<TPF>(vn, fmx, sc, isc, p.equalise);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = vn[r] * wn[r];
+        for (int r = 0; r < 8; ++r) v[r] = mk(vn[r].x, vn[r].y * sc) * wn[r];
         load_frames<N>(vn, p.t_len, xr, yr, fb + G + gi, t, fb + G + gi < f1);   // the next frame's samples fly under this one's passes
         F::run(v, z, t, tw);
         F::store_natural(v, z, t);
@@ -335,12 +385,15 @@ __global__ __launch_bounds__(256) void stft_loss_finalize_all_kernel(const StftF
     if (threadIdx.x == 0) out[0] = d;
 }
 
+constexpr int kFmxBytes = 32;      // head of the backward kernel's dynamic LDS: 4 (max |x|, max |y|) slots
+
 template <int N>
 __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
     typedef Fft<N> F;
     constexpr int TPF = F::TPF, G = F::G, H = N / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    c32* const zb = reinterpret_cast<c32*>(smem);
+    c32* const fmx = reinterpret_cast<c32*>(smem);           // kFmxBytes: one slot per wave (frame_scale)
+    c32* const zb = fmx + kFmxBytes / sizeof(c32);
     float* const accx = reinterpret_cast<float*>(zb + G * F::ZP);
     const int tid = threadIdx.x;
     const int gi = tid / TPF, t = tid - gi * TPF;
@@ -368,9 +421,12 @@ __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
     const float c1 = 2.f * invB, c2 = 2.f * A * invB * invB, invN = p.inv_n;
     // gradient w.r.t. the complex bins of X and Y for the pair (Z_k, Z_{n-k}); `gh` = grad_out x 0.5 for interior bins
     // (their Hermitian mirror carries the other half), x 1 for k = 0 and n/2.  sign(log(a+eps) - log(b+eps)) = sign(a - b).
+    // The frame pair is equalised (frame_scale): the transform carried s y, so Y = Y' / s; the gradient operand takes Wy / s
+    // (|Wy| ~ s |Wx| otherwise) and the imaginary part of the inverse transform is multiplied by s where it is added up.
+    float sc = 1.f, isc = 1.f;
     auto grads = [&](c32 z1, c32 z2, float gh, c32& gx, c32& gy) {
         const c32 X = mk(0.5f * (z1.x + z2.x), 0.5f * (z1.y - z2.y));
-        const c32 Y = mk(0.5f * (z1.y + z2.y), 0.5f * (z2.x - z1.x));
+        const c32 Y = mk((0.5f * isc) * (z1.y + z2.y), (0.5f * isc) * (z2.x - z1.x));
         const float a = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y), b = __builtin_amdgcn_sqrtf(Y.x * Y.x + Y.y * Y.y);
         const float d = a - b;
         const float sg = d > 0.f ? invN : (d < 0.f ? -invN : 0.f);
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
         const float db = gh * (-c1 * d - sg * __builtin_amdgcn_rcpf(b + eps));
         const float ra = a > 0.f ? da * __builtin_amdgcn_rcpf(a) : 0.f, rb = b > 0.f ? db * __builtin_amdgcn_rcpf(b) : 0.f;
         gx = X * ra;
-        gy = Y * rb;
+        gy = Y * (rb * isc);
     };
     __syncthreads();
     for (int ph = 0; ph < 4; ++ph) {
@@ -389,8 +445,9 @@ __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
             const int f = fb + 4 * gi;
             const bool valid = f <= fhi;
             c32 v[8];
+            frame_scale<TPF>(vn, fmx, sc, isc, p.equalise);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = vn[r] * wn[r];
+            for (int r = 0; r < 8; ++r) v[r] = mk(vn[r].x, vn[r].y * sc) * wn[r];
             load_frames<N>(vn, p.t_len, xr, yr, f + 4 * G, t, f + 4 * G <= fhi);
             F::run(v, z, t, tw);
             F::store_natural(v, z, t);
@@ -436,7 +493,7 @@ __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
                         if (loc >= 0 && loc < span) {
                             const c32 o = v[u * F::RF + r] * wo[u * F::RF + r];   // swapped: (d frame_y, d frame_x)
                             accx[loc] += o.y;
-                            accy[loc] += o.x;
+                            accy[loc] += o.x * sc;
                         }
                     }
             }
@@ -474,6 +531,11 @@ __global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
 constexpr int kTailMin = 6;       // a remainder shorter than this joins the previous workgroup (the last one must own the
                                   // whole right margin and the samples it folds onto: n + 1 samples = 4 blocks + 1)
 
+int equalise_on() {       // (read per call: the tests compare both settings in one process)
+    const char* e = getenv("RH_STFT_EQUALISE");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+
 bool shape_ok(int n_fft, int hop, int t_len, long rows) {
     return (n_fft == 128 || n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048) && hop * 4 == n_fft &&
            t_len > n_fft / 2 && (long)t_len + 2l * n_fft < 0x7fffffffl && rows > 0 && rows < 65536;
@@ -498,7 +560,7 @@ int rounds_of(int blocks, int first_frame_cut, int G) {
 }
 int choose_cb(int n_fft, int n_blocks, long rows) {
     const int G = 256 / (n_fft / 8), H = n_fft / 4;
-    const size_t zb = (size_t)G * (n_fft + n_fft / 8) * 8;
+    const size_t zb = (size_t)G * (n_fft + n_fft / 8) * 8 + kFmxBytes;
     int best = 0;
     double best_cost = 1e30;
     for (int m = 1; m <= 64; ++m) {
@@ -537,7 +599,7 @@ int launch_bwd(StftP p, hipStream_t stream) {
     typedef Fft<N> F;
     const int nch = chunks_of(p.n_blocks, p.cb);
     const int last = p.n_blocks - (nch - 1) * p.cb;                    // blocks of the last workgroup (>= all others)
-    const size_t lds = (size_t)F::G * F::ZP * sizeof(c32) + 2ul * (size_t)(last > p.cb ? last : p.cb) * (N / 4) * sizeof(float);
+    const size_t lds = kFmxBytes + (size_t)F::G * F::ZP * sizeof(c32) + 2ul * (size_t)(last > p.cb ? last : p.cb) * (N / 4) * sizeof(float);
     auto kern = stft_loss_bwd_kernel<N>;
     static bool once = false;
     if (!once) {
@@ -579,7 +641,7 @@ extern "C" int rh_stft_loss_plan_info(int32_t n_fft, int32_t t_len, int64_t rows
     const int last = n_blocks - (nch - 1) * cb;
     const int G = 256 / (n_fft / 8);
     out6[0] = fpw; out6[1] = (nf + fpw - 1) / fpw; out6[2] = cb; out6[3] = nch; out6[4] = last;
-    out6[5] = (int64_t)G * (n_fft + n_fft / 8) * 8 + 2l * (last > cb ? last : cb) * H * 4;
+    out6[5] = kFmxBytes + (int64_t)G * (n_fft + n_fft / 8) * 8 + 2l * (last > cb ? last : cb) * H * 4;
     return RH_OK;
 }
 
@@ -600,6 +662,7 @@ extern "C" int rh_stft_loss_fwd_f32(const float* x, const float* y, const float*
     p.x = x; p.y = y; p.win = window; p.tw = reinterpret_cast<const c32*>(twiddle);
     p.rows = (int)rows; p.t_len = t_len; p.n_frames = t_len / (n_fft / 4) + 1; p.eps = eps;
     p.fpw = fpw_of(n_fft, p.n_frames, rows);
+    p.equalise = equalise_on();
     p.part = static_cast<float*>(workspace);
     const int wx = (p.n_frames + p.fpw - 1) / p.fpw;
     int rc;
@@ -647,6 +710,7 @@ extern "C" int rh_stft_loss_bwd_f32(const float* x, const float* y, const float*
     p.sums = sums; p.gout = grad_out;
     p.inv_n = (float)(1.0 / ((double)rows * p.n_frames * (n_fft / 2 + 1)));
     p.dx = dx; p.dy = dy; p.accumulate = accumulate;
+    p.equalise = equalise_on();
     switch (n_fft) {
         case 128: return launch_bwd<128>(p, (hipStream_t)stream);
         case 256: return launch_bwd<256>(p, (hipStream_t)stream);

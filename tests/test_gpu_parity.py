@@ -1428,7 +1428,9 @@ def test_v3_validation_step_adain_eval_golden(golden_dir, dev):
         assert rel_l2(audio, call["audio"]) < TOL_E2E, rel_l2(audio, call["audio"])
         assert rel_l2(mean, call["mean"]) < TOL_E2E
         want = float(call["distance"])
-        assert abs(float(m.logged["validation"]) - want) <= 2e-4 * abs(want)
+        # (the distance contains log(|S| + 1e-7) of a random-init model's quiet output: its value moves by ~ 2e-4 under the
+        # 1e-5-class differences of y that the bound above admits)
+        assert abs(float(m.logged["validation"]) - want) <= 1e-3 * abs(want), (float(m.logged["validation"]), want)
         for a, bufs in zip(adains, call["buffers_after"]):
             for k, v in bufs.items():
                 have = getattr(a, k).cpu()
