@@ -5,8 +5,8 @@ on PCM that is already resident in HBM (288 GB hold ~900 h of 44.1 kHz mono int1
 
 The random draws follow the reference's distributions (uniform item / crop point, log-uniform pole frequency in
 [20, 2000] Hz at radius .99, U[0,1) dequantisation noise) but not its RNG streams; ``draws`` can be injected, which is
-how the parity test compares with scipy.signal.lfilter.  Reading the lmdb / protobuf container of
-scripts/preprocess.py is host I/O and stays out of scope.
+how the parity test compares with scipy.signal.lfilter.  ``load_lmdb_dataset`` reads the reference's on-disk container (the
+lmdb / ``AudioExample`` store of scripts/preprocess.py, rave_amd/lmdb_reader.py) into the int16 tensor this class samples from.
 """
 from __future__ import annotations
 
@@ -78,3 +78,51 @@ class GpuBatchFeed:
         L.check(L.lib.rh_feed_batch_i16_f32(L.ptr(self.pcm), L.ptr(off_d), L.ptr(coef_d), L.ptr(noise), rows, n_signal,
                                             self.bit_depth, L.ptr(out), L.stream()), "feed_batch")
         return out
+
+
+def load_lmdb_dataset(db_path: str, n_channels: Optional[int] = None, audio_key: str = "waveform", device=None,
+                      max_items: Optional[int] = None):
+    """The dataset ``scripts/preprocess.py`` wrote (``db_path/data.mdb`` + ``db_path/metadata.yaml``) as ONE int16 tensor
+    (items, channels, length) -- what ``rave.dataset.AudioDataset`` (rave/dataset.py:33-84) serves item by item:
+    every key of the environment in cursor order, ``np.frombuffer(ae.buffers['waveform'].data, int16).reshape(channels, -1)``.
+    Returns (pcm, info): ``pcm`` on ``device`` (None: host memory, pinned when a GPU is present) for ``GpuBatchFeed``;
+    ``info`` = dict(sr, channels, lazy, n_items, length, dropped).  Chunks are of equal length by construction
+    (scripts/preprocess.py:83-98 drops an incomplete tail); should a store hold other lengths, the items that differ from the
+    most common length are dropped and counted.  ``lazy`` stores (file paths decoded by ffmpeg on the fly, rave/dataset.py:
+    87-170) hold no PCM and are refused."""
+    import os
+    import yaml
+    from .lmdb_reader import LmdbReader, parse_audio_example
+    info = {}
+    meta_path = os.path.join(db_path, "metadata.yaml")
+    if os.path.exists(meta_path):
+        with open(meta_path) as f:
+            info = yaml.safe_load(f) or {}
+    if info.get("lazy"):
+        raise RuntimeError("rave_amd.data.load_lmdb_dataset: lazy dataset (audio decoded on the fly by ffmpeg): no PCM in the store")
+    ch = int(n_channels or info.get("channels", 1))
+    chunks = []
+    with LmdbReader(db_path) as db:
+        for k, v in db.items():
+            buffers, _ = parse_audio_example(v)
+            if audio_key not in buffers:
+                continue
+            raw = buffers[audio_key]["data"]
+            if len(raw) % (2 * ch):
+                raise RuntimeError(f"load_lmdb_dataset: item {k!r} holds {len(raw)} bytes, not a whole number of {ch}-channel int16 frames")
+            chunks.append(np.frombuffer(raw, dtype=np.int16).reshape(ch, -1).copy())
+            if max_items is not None and len(chunks) >= max_items:
+                break
+    if not chunks:
+        raise RuntimeError(f"load_lmdb_dataset: no '{audio_key}' buffers found under {db_path}")
+    lengths = [c.shape[1] for c in chunks]
+    common = max(set(lengths), key=lengths.count)
+    keep = [c for c in chunks if c.shape[1] == common]
+    pcm = torch.from_numpy(np.stack(keep, 0))
+    if device is not None:
+        pcm = pcm.to(device)
+    elif torch.cuda.is_available():
+        pcm = pcm.pin_memory()
+    out = dict(sr=int(info.get("sr", 44100)), channels=ch, lazy=False, n_items=len(keep), length=common,
+               dropped=len(chunks) - len(keep))
+    return pcm, out

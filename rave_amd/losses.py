@@ -80,3 +80,65 @@ class AudioDistanceV1(nn.Module):
         distance = ops.multiscale_stft_distance(xr, yr, [getattr(ms, f"window_{s}") for s in ms.scales], ms.scales,
                                                 float(self.log_epsilon))
         return {"spectral_distance": distance}
+
+
+# ---- the other distances of rave/core.py (:415-490); no shipped config selects them (v1 ... v3, discrete use AudioDistanceV1)
+class WaveformDistance(nn.Module):
+    """rave/core.py:433-440."""
+
+    def __init__(self, norm: str) -> None:
+        super().__init__()
+        self.norm = norm
+
+    def forward(self, x, y):
+        return mean_difference(y, x, self.norm)
+
+
+class SpectralDistance(nn.Module):
+    """rave/core.py:443-490: torchaudio Spectrogram(n_fft, hop = n_fft / 4, power, normalized, center=False) of both signals,
+    then ``mean_difference(y, x, norm)`` summed over the norms.  Beside the hot path and unused by the shipped configs: framing
+    is a strided view, the transform rocFFT (torch.fft), the reductions ATen -- library code on whatever device the signals
+    live on; nothing here is a HIP kernel of this package.  ``mel`` (torchaudio MelSpectrogram, hybrid.gin) is not built."""
+
+    def __init__(self, n_fft: int, sampling_rate: int, norm, power, normalized: bool, mel=None) -> None:
+        super().__init__()
+        if mel:
+            raise NotImplementedError("rave_amd SpectralDistance: the mel variant (torchaudio MelSpectrogram) is not built")
+        self.n_fft, self.hop, self.power, self.normalized = int(n_fft), int(n_fft) // 4, power, bool(normalized)
+        self.register_buffer("window", torch.hann_window(self.n_fft), persistent=False)
+        self.norm = (norm,) if isinstance(norm, str) else tuple(norm)
+
+    def spec(self, x: torch.Tensor) -> torch.Tensor:
+        """(..., T) -> (..., n_fft / 2 + 1, frames), torch.stft(center=False) layout."""
+        w = self.window.to(x.dtype)
+        fr = x.unfold(-1, self.n_fft, self.hop) * w                     # (..., frames, n_fft): no padding (center=False)
+        s = torch.fft.rfft(fr, dim=-1).transpose(-1, -2)
+        if self.normalized:
+            s = s / w.pow(2.0).sum().sqrt()
+        if self.power is None:
+            return s
+        return s.abs() if self.power == 1.0 else s.abs().pow(self.power)
+
+    def forward(self, x, y):
+        x = self.spec(x)
+        y = self.spec(y)
+        distance = 0
+        for norm in self.norm:
+            distance = distance + mean_difference(y, x, norm)
+        return distance
+
+
+class EncodecAudioDistance(nn.Module):
+    """rave/core.py:415-431."""
+
+    def __init__(self, scales, spectral_distance) -> None:
+        super().__init__()
+        self.waveform_distance = WaveformDistance(norm="L1")
+        self.spectral_distances = nn.ModuleList([spectral_distance(scale) for scale in scales])
+
+    def forward(self, x, y):
+        waveform_distance = self.waveform_distance(x, y)
+        spectral_distance = 0
+        for dist in self.spectral_distances:
+            spectral_distance = spectral_distance + dist(x, y)
+        return {"waveform_distance": waveform_distance, "spectral_distance": spectral_distance}

@@ -443,3 +443,33 @@ def test_stft_loss_algorithm_restatement_vs_torch_stft():
         assert abs(dist - float(d)) <= 1e-12 * abs(float(d))
         assert np.abs(dx - x.grad.numpy()).max() <= 1e-10 * np.abs(x.grad.numpy()).max()
         assert np.abs(dy - y.grad.numpy()).max() <= 1e-10 * np.abs(y.grad.numpy()).max()
+
+
+@pytest.mark.skipif(not _have_reference(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("power,normalized,norms", [(1, True, ("L1", "L2")), (2, False, "L2"), (None, True, "L1")])
+def test_spectral_and_encodec_distances_equal_the_reference_classes(power, normalized, norms):
+    """rave/core.py:415-490 (the rest of SURVEY section 8f #1): rave_amd.losses.SpectralDistance / WaveformDistance /
+    EncodecAudioDistance against the reference's own classes (on the torchaudio shim), values and gradients."""
+    from functools import partial
+    from ref_import import import_reference
+    import_reference()
+    from rave import core
+    from rave_amd import losses
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 1, 6000, generator=g)
+    y = (x + 0.1 * torch.randn(2, 1, 6000, generator=g))
+    kw = dict(sampling_rate=44100, norm=norms, power=power, normalized=normalized)
+    for n_fft in (256, 1024):
+        a = core.SpectralDistance(n_fft, **kw)
+        b = losses.SpectralDistance(n_fft, **kw)
+        ya, yb = y.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        da, db = a(x, ya), b(x, yb)
+        assert abs(float(da) - float(db)) <= 1e-5 * abs(float(da))
+        da.backward(); db.backward()
+        assert rel_l2(yb.grad, ya.grad) < 1e-5
+    ea = core.EncodecAudioDistance([256, 512], partial(core.SpectralDistance, **kw))
+    eb = losses.EncodecAudioDistance([256, 512], partial(losses.SpectralDistance, **kw))
+    ra, rb = ea(x, y), eb(x, y)
+    assert set(ra) == set(rb) == {"waveform_distance", "spectral_distance"}
+    for k in ra:
+        assert abs(float(ra[k]) - float(rb[k])) <= 1e-5 * abs(float(ra[k])), k
