@@ -198,7 +198,7 @@ def _pmc_traffic(kernel_name):
     collected on; a different library is loaded now -> traffic null + a note (the figure would silently be stale)."""
     fam = {"conv_x6_kernel": "conv_x6(fwd+dgrad)", "wgrad_x6_kernel": "wgrad_x6", "wgrad_dma_kernel": "wgrad_f32",
            "conv_igemm_dma_kernel": "conv_f32(fwd+dgrad)"}.get(kernel_name)
-    for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json"):
+    for name in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

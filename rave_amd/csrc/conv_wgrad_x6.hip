@@ -330,11 +330,14 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     const int BM = 32 * pl->tm * pl->wm, BN = 64 * (4 / pl->wm);
     pl->rt = rh_cdiv(w.M, BM);
     pl->ct = rh_cdiv(p->N, BN);
-    // K slices: two rounds of workgroups (1024) when the weight tensor has many tiles (the second round's matrix work
-    // covers the first round's partial-tile stores), one round (512) when it has few -- every extra slice is another
-    // copy of the whole weight tensor written and re-read (measured per layer, profiles/round2_layer_table_b32.txt)
+    // K slices: one round of workgroups (512) -- every extra slice is another copy of the whole weight tensor written and
+    // re-read.  (Rounds 2-4 ran two rounds, 1024, when the weight tensor has >= 32 tiles: measured per layer then, slower
+    // in the step now.)
     static const int target_env = [] { const char* e2 = getenv("RH_WGRAD_X6_BLOCKS"); return e2 ? atoi(e2) : 0; }();
-    const int target = target_env > 0 ? target_env : (pl->rt * pl->ct >= 32 ? 1024 : 512);
+    // (round 5: -1 = one round of the RESIDENT workgroups -- 64-row wave tiles fit three per CU, the others two)
+    // round 5, A/B on two boxes (tools/debug/exp_r5_*.sh): 512 everywhere 10.02-10.04 ms per step against 10.08-10.09 with two
+    // rounds (1024) for the many-tile layers, 10.11 with "resident slots" (768 for TM = 2), 10.10 at 384, 10.35 at 640
+    const int target = target_env > 0 ? target_env : (target_env < 0 ? (pl->tm == 2 ? 768 : 512) : 512);
     int Z = rh_cdiv(target, pl->rt * pl->ct);
     const int zmax = p->total_steps / 4 > 0 ? p->total_steps / 4 : 1;     // at least 4 steps (128 positions) per slice
     if (Z > zmax) Z = zmax;

@@ -387,8 +387,16 @@ __global__ __launch_bounds__(256) void stft_loss_finalize_all_kernel(const StftF
 
 constexpr int kFmxBytes = 32;      // head of the backward kernel's dynamic LDS: 4 (max |x|, max |y|) slots
 
+// Workgroups per CU the backward kernel is compiled for: 3 (<= 168 VGPRs), or -- RH_STFT_BWD_OCC2 builds, an experiment -- 2 for
+// the transforms that span several waves, whose equaliser (cross-wave maximum) pushed them over 168 registers (5-13 spilled)
+#ifdef RH_STFT_BWD_OCC2
+constexpr int stft_bwd_occ(int n) { return n >= 1024 ? 2 : 3; }
+#else
+constexpr int stft_bwd_occ(int) { return 3; }
+#endif
+
 template <int N>
-__global__ __launch_bounds__(256, 3) void stft_loss_bwd_kernel(const StftP p) {
+__global__ __launch_bounds__(256, stft_bwd_occ(N)) void stft_loss_bwd_kernel(const StftP p) {
     typedef Fft<N> F;
     constexpr int TPF = F::TPF, G = F::G, H = N / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -573,7 +581,8 @@ int choose_cb(int n_fft, int n_blocks, long rows) {
         const size_t lds = zb + 2ul * big * H * 4;
         if (lds > 150 * 1024) break;
         int per_cu = (int)(160 * 1024 / lds);
-        per_cu = per_cu > 3 ? 3 : per_cu;                               // __launch_bounds__(256, 3): <= 168 VGPRs
+        const int occ = stft_bwd_occ(n_fft);
+        per_cu = per_cu > occ ? occ : per_cu;                           // __launch_bounds__(256, occ)
         const double wgs = (double)rows * nch, slots = 256.0 * per_cu;
         const int r_first = rounds_of(nch == 1 ? n_blocks : cb, 3, G);   // the first workgroup has no frames to its left
         const int r_mid = nch > 2 ? rounds_of(cb, 0, G) : 0;

@@ -527,7 +527,13 @@ class GraphedTrainingStep:
                     mod.refresh_host_caches()
             m.set_phase_flags_eagerly()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            import os
+            kw = {}
+            if os.environ.get("RH_GRAPH_PRIORITY", "0") == "1":
+                # experiment: record the step on a HIGH-priority stream, so that the data-gradient chain (the critical path)
+                # wins the arbitration against the weight-gradient branch, which forks onto a default-priority stream
+                kw["stream"] = torch.cuda.Stream(priority=-1)
+            with torch.cuda.graph(g, **kw):
                 if self.before_step is not None:
                     self.before_step()
                 logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True, **self.sync_kw)

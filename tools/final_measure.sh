@@ -1,7 +1,7 @@
-# end-of-round measurement batch (run on the GPU box through gpurun); outputs under gpurun_out/r4/ (copied into profiles/round4_*)
+# end-of-round measurement batch (run on the GPU box through gpurun); outputs under $O (default gpurun_out/r5f/; copied into profiles/round5_*)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r4; mkdir -p $O
+O=${O:-gpurun_out/r5f}; mkdir -p $O
 PARTS=${PARTS:-all}
 has() { [ "$PARTS" = all ] || echo " $PARTS " | grep -q " $1 "; }
 if has probes; then      # (binaries: bash tools/probe/build.sh in the build container)
@@ -42,6 +42,24 @@ if has prof; then
   f=$(find $O/profg -name "*.db" | head -1)
   [ -n "$f" ] && python tools/prof_summary.py $f > $O/kernel_stats_step_b32_graph.md 2>&1
   rm -rf $O/profg
+fi
+if has count; then    # dispatches per REPLAYED step: two graph runs that differ only in the number of timed steps (everything else --
+                      # warm-up, capture, set-up -- cancels in the difference)
+  for n in 20 60; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/cnt$n -o p -- python $GRAFT_REPO_ROOT/bench.py --steps $n --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/$O/cnt$n.log 2>&1 < /dev/null)
+    f=$(find $O/cnt$n -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f > $O/cnt$n.md 2>&1; rm -rf $O/cnt$n
+  done
+  python - <<PY > $O/dispatches_per_step.txt
+import re
+def tot(p):
+    t = open(p).read().strip().splitlines()[-1]
+    m = re.search(r"total kernel time ([0-9.]+) ms over (\d+) dispatches", t)
+    return float(m.group(1)), int(m.group(2))
+(a_ms, a_n), (b_ms, b_n) = tot("$O/cnt20.md"), tot("$O/cnt60.md")
+print(f"graph replay, v2 VAE-phase step, batch 32 x 65536: {(b_n - a_n) / 40:.1f} dispatches and {(b_ms - a_ms) / 40:.3f} ms of kernel time per replayed step")
+print(f"(rocprofv3 --kernel-trace of bench.py --steps 60 minus --steps 20: {b_n} - {a_n} dispatches, {b_ms:.2f} - {a_ms:.2f} ms)")
+PY
+  cat $O/dispatches_per_step.txt
 fi
 if has prof2; then     # rocprofv3 kernel stats of the discrete (eager) and v3 (graph) GAN-phase steps
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_v3 -o p -- python $GRAFT_REPO_ROOT/bench.py --config v3 --phase gan --batch 16 --steps 8 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_v3.log 2>&1 < /dev/null)
