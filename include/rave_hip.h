@@ -341,6 +341,14 @@ int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const flo
 int64_t rh_vq_loss_partials(int64_t n_vectors);
 int rh_vq_assign_f32(const float* x, const float* embed, int64_t n_vectors, int32_t dim, int32_t codebook_size,
                      int64_t* indices, float* residual, float* quantized_sum, float* loss_partials, rh_stream_t stream);
+/* The same step with caller-provided scratch: with rh_vq_assign_workspace_bytes(...) > 0 bytes of it the distance search
+ * (rave/quantization.py:131-136) runs on the f32 matrix cores -- the same fmaf chains, hence the same distances, indices
+ * and loss partials as the one-launch kernel -- in two launches; 0 bytes / NULL = rh_vq_assign_f32 (residual may alias x
+ * on either path). */
+int64_t rh_vq_assign_workspace_bytes(int64_t n_vectors, int32_t dim, int32_t codebook_size);
+int rh_vq_assign_ws_f32(const float* x, const float* embed, int64_t n_vectors, int32_t dim, int32_t codebook_size,
+                        int64_t* indices, float* residual, float* quantized_sum, float* loss_partials, void* workspace,
+                        int64_t workspace_bytes, rh_stream_t stream);
 /* Training-time codebook update (:165-179): cluster_size / embed_avg EMAs from per-code counts and ordered
  * vector sums (deterministic), then embed = embed_avg / (laplace_smoothing(cluster_size) * sum). */
 int rh_vq_ema_update_f32(const float* x, const int64_t* indices, int64_t n_vectors, int32_t dim, int32_t codebook_size,

@@ -103,6 +103,8 @@ def _load() -> C.CDLL:
         "rh_feed_batch_i16_f32": ([P, P, P, P, I32, I32, I32, P, P], C.c_int),
         "rh_vq_loss_partials": ([I64], I64),
         "rh_vq_assign_f32": ([P, P, I64, I32, I32, P, P, P, P, P], C.c_int),
+        "rh_vq_assign_workspace_bytes": ([I64, I32, I32], I64),
+        "rh_vq_assign_ws_f32": ([P, P, I64, I32, I32, P, P, P, P, P, I64, P], C.c_int),
         "rh_vq_ema_update_f32": ([P, P, I64, I32, I32, F, F, P, P, P, P], C.c_int),
         "rh_pqmf_analysis_fwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),
         "rh_pqmf_analysis_bwd_f32": ([P, P, I32, I32, I32, I32, I32, I32, P, P], C.c_int),

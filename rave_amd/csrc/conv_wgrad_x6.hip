@@ -333,7 +333,8 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     // K slices: one round of workgroups (512) -- every extra slice is another copy of the whole weight tensor written and
     // re-read.  (Rounds 2-4 ran two rounds, 1024, when the weight tensor has >= 32 tiles: measured per layer then, slower
     // in the step now.)
-    static const int target_env = [] { const char* e2 = getenv("RH_WGRAD_X6_BLOCKS"); return e2 ? atoi(e2) : 0; }();
+    const char* te = getenv("RH_WGRAD_X6_BLOCKS");      // (read per call: the fused-tail test asks for the finer split)
+    const int target_env = te ? atoi(te) : 0;
     // (round 5: -1 = one round of the RESIDENT workgroups -- 64-row wave tiles fit three per CU, the others two)
     // round 5, A/B on two boxes (tools/debug/exp_r5_*.sh): 512 everywhere 10.02-10.04 ms per step against 10.08-10.09 with two
     // rounds (1024) for the many-tile layers, 10.11 with "resident slots" (768 for TM = 2), 10.10 at 384, 10.35 at 640

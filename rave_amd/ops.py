@@ -489,8 +489,15 @@ def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s):
                                               nbytes, s)
 
     rc = _launch("conv_wgrad", d, lambda: run(dw, db))
-    if rc == 0:
-        _shadow("wgrad", d, lambda o: run(o[0], o[1]), [dw, db])
+    if rc == 0 and _SHADOW is not None:
+        def run_exact(o):
+            # the exact-f32 kernels plan their own K slices: their scratch is sized under THEIR plan (it used to fit into the
+            # bf16x6 path's by accident, while that path cut K into twice as many slices)
+            nb2 = L.lib.rh_conv1d_workspace_bytes(C.byref(d))
+            ws2 = torch.empty(max(nb2, 4) // 4, device=dy.device, dtype=torch.float32)
+            return L.lib.rh_conv1d_bwd_weight_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(o[0]), L.ptr(o[1]), L.ptr(ws2),
+                                                  nb2, s)
+        _shadow("wgrad", d, run_exact, [dw, db])
     return rc
 
 

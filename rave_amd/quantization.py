@@ -34,8 +34,10 @@ def _assign(x: torch.Tensor, embed: torch.Tensor, residual, qsum, want_loss: boo
     k = embed.shape[0]
     ind = torch.empty(n, device=x.device, dtype=torch.int64)
     parts = torch.empty(L.lib.rh_vq_loss_partials(n), device=x.device, dtype=torch.float32) if want_loss else None
-    L.check(L.lib.rh_vq_assign_f32(L.ptr(x), L.ptr(embed), n, d, k, L.ptr(ind), L.ptr(residual), L.ptr(qsum), L.ptr(parts),
-                                   L.stream()), "vq_assign")
+    nbytes = L.lib.rh_vq_assign_workspace_bytes(n, d, k)      # > 0: distance search on the f32 matrix cores (vq.hip, round 5)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes > 0 else None
+    L.check(L.lib.rh_vq_assign_ws_f32(L.ptr(x), L.ptr(embed), n, d, k, L.ptr(ind), L.ptr(residual), L.ptr(qsum), L.ptr(parts),
+                                      L.ptr(ws), nbytes, L.stream()), "vq_assign")
     return ind, parts
 
 

@@ -675,7 +675,8 @@ def test_weight_gradient_through_weight_norm_in_one_launch_equals_the_two_launch
     g0 = (torch.rand(v0.shape[0], 1, 1, generator=gen) + 0.5).to(dev)
 
     def run(fused, x6):
-        with _Env(RH_WN_FUSED=fused, RH_WGRAD_X6=x6, RH_BWD_SIDE_STREAM=0):
+        # (RH_WGRAD_X6_BLOCKS=1024: the finer K split of rounds 2-4, so that every case here really has slices to reduce)
+        with _Env(RH_WN_FUSED=fused, RH_WGRAD_X6=x6, RH_BWD_SIDE_STREAM=0, RH_WGRAD_X6_BLOCKS=1024):
             v, g = v0.clone().requires_grad_(True), g0.clone().requires_grad_(True)
             y = R.conv1d(x, v, None, geom=geom, weight_g=g)
             cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(12)).to(dev)

