@@ -570,10 +570,16 @@ def main():
                                          "the compute stream (HIP events around GradReducer.finish() in eager steps)",
                       "bytes_packed_total": red_gen.bytes_packed + (red_dis.bytes_packed if red_dis else 0),
                       "bytes_packed_per_step": (red_gen.bytes_packed + (red_dis.bytes_packed if red_dis else 0)) // nst,
+                      "bytes_reduced_total": tot, "bytes_overlapped_total": ovl,
+                      "allreduces_issued_from_side_stream": red_gen.side_issued + (red_dis.side_issued if red_dis else 0),
+                      "step_mode": out["step_mode"],
+                      "phase_note": ("every N runs the SAME per-GPU workload (BASELINE configs[1]: VAE-phase step, 32 clips per GPU) so "
+                                     "that the scaling curve compares like with like; configs[2]'s VAE+GAN alternation: --phase gan"),
                       "overlap_fraction": ovl / tot if tot else None,
                       "overlap_note": "share of the all-reduce bytes issued from a gradient hook, i.e. while backward still ran "
                                       "(counted over the steps that ran Python: warm-up, capture, instrumented eager steps)",
-                      "buffer_broadcast_bytes_per_step": bufsync.bytes_per_sync}
+                      "buffer_broadcast_bytes_per_step": bufsync.bytes_per_sync,
+                      "buffer_bytes_static_not_resent": bufsync.bytes_static}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
