@@ -47,8 +47,15 @@ struct Wx6P {
     int total_steps, steps_per_z;
     unsigned r_bytes, s_bytes;
     int minoff, maxoff;
+    int p8, cpb, chmax;         // plane mode (PL): octets of a channel image, channel pitch in bytes, channel images reserved
     int off[kMaxTaps];
 };
+
+__device__ __forceinline__ u32x4 wx6_lds_read_b128_any(unsigned addr) {      // 16 bytes at any 2-byte alignment (1.4x the aligned cost)
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 
 // LeakyReLU (slope in [0, 1]; 1 = none) + exact 3-way bf16 split of 8 samples -> three 16-byte fragments, ~7.5 VALU
 // instructions per sample: max(x, slope x), two mask / subtract rounds, one byte permute per packed pair.  VALU work
@@ -79,8 +86,15 @@ constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
 // PART: the last column tile holds whole 32-column MFMA tiles past the end of the weight tensor -- their columns are
 // neither converted nor multiplied (a separate instantiation: the two uniform branches cost 14 VGPRs, which would take the
 // 64-row variants from three workgroups per CU to two)
-template <int TM, int WM, int WN, bool AV, bool PART>
-__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
+// PL ("planes", round 5): the S operand of a stride-1 layer with several taps is staged ONCE PER POSITION -- per step the
+// 32 + (maxoff - minoff) positions of every channel the column tile touches, converted into bf16 ELEMENT planes
+// [piece][channel][position] -- and the fragment of column (c, t) is the 16-byte LDS read at channel c's image + the tap's
+// element offset: any 2-byte alignment, which ds_read_b128 serves at 1.4x the aligned cost (tools/probe/lds_unaligned.hip; the
+// technique of wgrad2d_x6.hip).  A tap is an address offset; nothing is converted per tap: C = 96, k = 3 converts
+// (96 + 91) x 32 samples per step instead of (96 + 256) x 32, dilation 9 (96 + 134) x 32; C >= 192 (192 + 46) instead of
+// (192 + 128).  Same products in the same order: bit-identical weight gradients.
+template <int TM, int WM, int WN, bool AV, bool PART, bool PL>
+__global__ __launch_bounds__(256, (TM == 2 && WM == 2) ? 3 : 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 64 * WN;
     // fragments of ONE k block: [g][piece][rows], with 4 fragments of padding per g block.  The OCT = 4 lanes that convert
@@ -90,10 +104,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     constexpr int A_GS = 3 * BM + 4, B_GS = 3 * BN + 4;                   // g stride
     constexpr int A_UNITS = 2 * A_GS, B_UNITS = 2 * B_GS;                 // k-block stride
     constexpr int OCT = 2 * kKS;                                          // 8-sample octets per row and step
-    constexpr int NA = (OCT * BM + 255) / 256, NB = (OCT * BN + 255) / 256;   // tasks per thread and step
+    constexpr int NA = (OCT * BM + 255) / 256;                                // tasks per thread and step
+    // PL: (channel, octet) tasks -- at most BN / 2 + 2 channel images of <= 7 octets
+    constexpr int NB = PL ? ((BN / 2 + 2) * 7 + 255) / 256 : (OCT * BN + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* const a_st = reinterpret_cast<u32x4*>(smem_raw);              // [kKS][g][piece][BM]
-    u32x4* const b_st = a_st + kKS * A_UNITS;                             // [kKS][g][piece][BN]
+    u32x4* const b_st = a_st + kKS * A_UNITS;                             // [kKS][g][piece][BN]   (PL: [piece][channel][position] bf16)
+    const unsigned b_img = (unsigned)(size_t)b_st;                        // LDS byte address of the plane image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,17 +135,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         apos[q] = 8 * o;
         aoff[q] = ok ? (unsigned)(((m0 + m) * p.r_row + 8 * o) * 4) : kOOB;
     }
+    const int c_lo = PL ? n0 / p.T : 0;                                                  // first channel of this column tile
+    const int n_ch = PL ? min(p.N - 1, n0 + BN - 1) / p.T - c_lo + 1 : 0;                // channel images it needs
+    const unsigned b_piece = PL ? (unsigned)(p.chmax * p.cpb) : 0u;                      // bytes between the pieces of the image
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int u = tid + 256 * q;
-        const int o = u % OCT, col = u / OCT;
-        const int cc = (n0 + col) / p.T, t = (n0 + col) - cc * p.T;
-        const bool ok = col < BN && n0 + col < p.N;
-        // columns past the end of the weight tensor convert nothing (their LDS slots keep whatever they hold: a column of
-        // the B operand only reaches its own output column, which is never stored)
-        bdst[q] = (PART ? ok : col < BN) ? (o >> 1) * B_UNITS + (o & 1) * B_GS + col : -1;
-        bp0[q] = 8 * o * p.is + (ok ? p.off[t] : 0);                  // position of sample 0 relative to n * is
-        boff[q] = ok ? (unsigned)((cc * p.s_row + bp0[q]) * 4) : kOOB;
+        if constexpr (PL) {
+            const int ch = u / p.p8, o = u - ch * p.p8;
+            const bool ok = ch < n_ch;
+            bdst[q] = ok ? ch * p.cpb + o * 16 : -1;                                     // byte offset inside a piece
+            bp0[q] = p.minoff + 8 * o;                                                   // position of sample 0 relative to n
+            boff[q] = ok ? (unsigned)(((c_lo + ch) * p.s_row + bp0[q]) * 4) : kOOB;
+        } else {
+            const int o = u % OCT, col = u / OCT;
+            const int cc = (n0 + col) / p.T, t = (n0 + col) - cc * p.T;
+            const bool ok = col < BN && n0 + col < p.N;
+            // columns past the end of the weight tensor convert nothing (their LDS slots keep whatever they hold: a column of
+            // the B operand only reaches its own output column, which is never stored)
+            bdst[q] = (PART ? ok : col < BN) ? (o >> 1) * B_UNITS + (o & 1) * B_GS + col : -1;
+            bp0[q] = 8 * o * p.is + (ok ? p.off[t] : 0);                  // position of sample 0 relative to n * is
+            boff[q] = ok ? (unsigned)((cc * p.s_row + bp0[q]) * 4) : kOOB;
+        }
+    }
+    // PL: byte offset of this lane's two columns inside a piece of the image: channel image + element offset of the tap
+    unsigned bcolb[2] = {0u, 0u};
+    if constexpr (PL) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int n = n0 + wn * 64 + tn * 32 + j;
+            if (n < p.N) {
+                const int cc = n / p.T, t = n - cc * p.T;
+                bcolb[tn] = (unsigned)((cc - c_lo) * p.cpb + (p.off[t] - p.minoff) * 2);
+            }
+        }
     }
 
     f32x16 acc[TM][2];
@@ -147,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         const unsigned rs = (unsigned)((b * p.M * p.r_row + n) * 4);
         const unsigned ss = (unsigned)((b * p.C * p.s_row + n * p.is) * 4);
         const bool r_tail = n + SPAN > p.r_row;                                     // uniform
-        const bool s_edge = n * p.is + p.minoff < 0 || (n + SPAN - 1) * p.is + p.maxoff >= p.s_valid || r_tail;
+        const bool s_edge = PL ? (n + p.minoff < 0 || n + p.minoff + 8 * p.p8 > p.s_valid || r_tail)
+                               : (n * p.is + p.minoff < 0 || (n + SPAN - 1) * p.is + p.maxoff >= p.s_valid || r_tail);
         // the whole element offset goes into the per-lane operand (the bounds check must see it: a tap offset alone
         // can be negative for a valid sample), nothing into the scalar offset
 #pragma unroll
@@ -201,8 +242,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         for (int q = 0; q < NA; ++q)
             if (adst[q] >= 0) emit(ra[q], p.r_slope, a_st + adst[q], BM);
 #pragma unroll
-        for (int q = 0; q < NB; ++q)
-            if (bdst[q] >= 0) emit(rb[q], p.s_slope, b_st + bdst[q], BN);
+        for (int q = 0; q < NB; ++q) {
+            if (bdst[q] < 0) continue;
+            if constexpr (PL) emit(rb[q], p.s_slope, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(b_st) + bdst[q]), (int)(b_piece >> 4));
+            else emit(rb[q], p.s_slope, b_st + bdst[q], BN);
+        }
     };
 
     const int st0 = z * p.steps_per_z;
@@ -229,24 +273,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
             for (int kb = 0; kb < kKS; ++kb) {
                 const u32x4* al = a_st + kb * A_UNITS + arow;
                 const u32x4* bl = b_st + kb * B_UNITS + bcol;
-                bf16x8 bfr[2][3], afr[TM][3];
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)           // (a dead tile's slots hold stale data: read, never multiplied)
-#pragma unroll
-                    for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
+                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+                bf16x8 afr[TM][3];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
-                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+                if constexpr (PL) {
+                    // the 8 positions 16 kb + 8 g .. + 7 of the column's channel image, shifted by its tap: an unaligned read.
+                    // One column tile at a time (three fragments in registers, not six): every accumulator still receives its
+                    // six products in the same order.
+                    const unsigned bo = b_img + (unsigned)((kb * 16 + g * 8) * 2);
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                    for (int tn = 0; tn < 2; ++tn) {
+                        if (tn == 1 && !live2) break;                                   // wave-uniform
+                        u32x4 b0 = wx6_lds_read_b128_any(bo + bcolb[tn]), b1 = wx6_lds_read_b128_any(bo + bcolb[tn] + b_piece),
+                              b2 = wx6_lds_read_b128_any(bo + bcolb[tn] + 2u * b_piece);
+                        // (the compiler does not count the asm reads: wait for everything LDS has in flight)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2));
+                        const bf16x8 bf[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[0][SB[q]], acc[tm][0], 0, 0, 0);
-                        if (live2)
-                            acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[1][SB[q]], acc[tm][1], 0, 0, 0);
+                        for (int q = 0; q < 6; ++q)
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bf[SB[q]], acc[tm][tn], 0, 0, 0);
                     }
+                } else {
+                    bf16x8 bfr[2][3];
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)           // (a dead tile's slots hold stale data: read, never multiplied)
+#pragma unroll
+                        for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[0][SB[q]], acc[tm][0], 0, 0, 0);
+                            if (live2)
+                                acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[1][SB[q]], acc[tm][1], 0, 0, 0);
+                        }
+                }
             }
         }
         __syncthreads();                 // every wave is done reading this step's fragments
@@ -285,6 +351,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 
 struct Wx6Plan {
     int tm, wm, rt, ct, Z, steps_per_z;
+    int planes;              // the S operand staged once per position as bf16 element planes (PL)
+    size_t lds;
 };
 
 bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
@@ -330,6 +398,20 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     const int BM = 32 * pl->tm * pl->wm, BN = 64 * (4 / pl->wm);
     pl->rt = rh_cdiv(w.M, BM);
     pl->ct = rh_cdiv(p->N, BN);
+    // plane mode (round 5): stride-1 layers with several taps whose reach fits the image (<= 7 octets per channel: the
+    // k = 3 units up to dilation 9 -- reach 18 --, the k = 7 stem).  RH_WGRAD_X6_PLANES=0: the per-tap conversion of rounds 2-4.
+    {
+        const char* pe = getenv("RH_WGRAD_X6_PLANES");          // read per call (the tests compare both)
+        const bool on = !(pe && pe[0] == '0');
+        const int reach = w.maxoff - w.minoff;
+        const int p8 = (32 + reach + 7) / 8;
+        pl->planes = on && w.is == 1 && w.T >= 2 && reach >= 0 && p8 <= 7 && 4l * (w.s_row + 64) * w.C * w.B < 0x7fffffffl;
+        p->p8 = p8;
+        p->cpb = 16 * ((p8 & 1) ? p8 : p8 + 1);                 // odd number of 16-byte slots: channel images start on different banks
+        p->chmax = BN / w.T + 2;
+    }
+    const size_t a_bytes = (size_t)kKS * 2 * (3 * BM + 4) * 16;
+    pl->lds = a_bytes + (pl->planes ? (size_t)3 * p->chmax * p->cpb + 32 : (size_t)kKS * 2 * (3 * BN + 4) * 16);
     // K slices: one round of workgroups (512) -- every extra slice is another copy of the whole weight tensor written and
     // re-read.  (Rounds 2-4 ran two rounds, 1024, when the weight tensor has >= 32 tiles: measured per layer then, slower
     // in the step now.)
@@ -349,15 +431,20 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     return true;
 }
 
-template <int TM, int WM, bool AV, bool PART>
-void go3(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
-    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM, AV, PART>;
-    constexpr size_t lds = kKS * (2 * (3 * 32 * TM * WM + 4) + 2 * (3 * 64 * (4 / WM) + 4)) * 16;
+template <int TM, int WM, bool AV, bool PART, bool PL>
+void go4(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    auto kern = wgrad_x6_kernel<TM, WM, 4 / WM, AV, PART, PL>;
     static std::once_flag once;
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    rh_launch_main(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), lds, stream, p);
+    rh_launch_main(kern, dim3(pl.ct, pl.rt, pl.Z), dim3(256), pl.lds, stream, p);
+}
+
+template <int TM, int WM, bool AV, bool PART>
+void go3(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
+    if (pl.planes) go4<TM, WM, AV, PART, true>(p, pl, stream);
+    else go4<TM, WM, AV, PART, false>(p, pl, stream);
 }
 
 template <int TM, int WM, bool AV>

@@ -646,6 +646,53 @@ def test_gradient_accumulation_over_two_backward_calls_with_the_side_stream(dev)
             assert torch.equal(a, b)
 
 
+PLANE_CASES = [
+    # (name, batch, c_in, c_out, length, kernel, geometry kwargs)
+    ("unit_k3_d1_c96", 8, 96, 96, 4096, 3, dict(dilation=1, pad_left=1, pad_right=1, act=1, slope=0.2)),
+    ("unit_k3_d9_c96", 8, 96, 96, 4096, 3, dict(dilation=9, pad_left=9, pad_right=9, act=1, slope=0.2)),
+    ("unit_k3_d9_c96_causal_ragged", 3, 96, 96, 4001, 3, dict(dilation=9, pad_left=18, pad_right=0, act=1, slope=0.2)),
+    ("unit_k3_d3_c192", 8, 192, 192, 1024, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2)),
+    ("unit_k3_d9_c384", 8, 384, 384, 256, 3, dict(dilation=9, pad_left=9, pad_right=9, act=1, slope=0.2)),
+    ("unit_k3_d1_c768", 32, 768, 768, 64, 3, dict(dilation=1, pad_left=1, pad_right=1, act=1, slope=0.2)),
+    ("stem_16_96_k7", 8, 16, 96, 4096, 7, dict(pad_left=3, pad_right=3)),
+    ("head_1536_256_k3", 32, 1536, 256, 32, 3, dict(pad_left=1, pad_right=1, act=1, slope=0.2)),
+    ("short_rows_k3_c128", 5, 128, 160, 37, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2)),
+]
+
+
+@pytest.mark.parametrize("case", PLANE_CASES, ids=[c[0] for c in PLANE_CASES])
+def test_weight_gradient_with_the_input_staged_once_per_position_is_bit_identical(dev, case):
+    """wgrad_x6_kernel's plane mode (round 5: the input of a stride-1 multi-tap layer converted ONCE per position into bf16
+    element planes, a tap = an unaligned 16-byte LDS read) against the per-tap conversion of rounds 2-4 (RH_WGRAD_X6_PLANES=0):
+    the same products in the same order -> the weight (and bias) gradients must be the SAME BITS; and against the exact-f32 MFMA
+    kernel to 2e-6.  Geometries: every k = 3 / k = 7 layer class of the v2 generator, causal pads, ragged row lengths."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    _, batch, c_in, c_out, length, k, kw = case
+    gen = torch.Generator().manual_seed(31)
+    geom = ConvGeom(**kw)
+    x = torch.randn(batch, c_in, length, generator=gen).to(dev)
+    w0 = (torch.randn(c_out, c_in, k, generator=gen) * 0.05).to(dev)
+    b0 = torch.randn(c_out, generator=gen).to(dev)
+
+    def run(**env):
+        with _Env(RH_BWD_SIDE_STREAM=0, **env):
+            w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = R.conv1d(x, w, b, geom=geom)
+            cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(32)).to(dev)
+            y.backward(cot)
+            torch.cuda.synchronize()
+            return w.grad.clone(), b.grad.clone()
+
+    dw1, db1 = run(RH_WGRAD_X6_PLANES=1)
+    dw0, db0 = run(RH_WGRAD_X6_PLANES=0)
+    assert torch.isfinite(dw1).all()
+    assert torch.equal(dw1, dw0), rel_l2(dw1, dw0)
+    assert torch.equal(db1, db0)
+    dwf, dbf = run(RH_WGRAD_X6=0)
+    assert rel_l2(dw1, dwf) < 2e-6 and rel_l2(db1, dbf) < 2e-6
+
+
 WN_TAIL_CASES = [
     # (name, batch, c_in, c_out, length, kernel, geometry kwargs, transposed)
     ("unit_k3_c96", 8, 96, 96, 4096, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2), False),
