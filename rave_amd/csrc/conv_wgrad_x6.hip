@@ -92,7 +92,13 @@ constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
 // element offset: any 2-byte alignment, which ds_read_b128 serves at 1.4x the aligned cost (tools/probe/lds_unaligned.hip; the
 // technique of wgrad2d_x6.hip).  A tap is an address offset; nothing is converted per tap: C = 96, k = 3 converts
 // (96 + 91) x 32 samples per step instead of (96 + 256) x 32, dilation 9 (96 + 134) x 32; C >= 192 (192 + 46) instead of
-// (192 + 128).  Same products in the same order: bit-identical weight gradients.
+// (192 + 128).  Same products in the same order: bit-identical weight gradients (tests/test_gpu_dispatch.py).
+// MEASURED SLOWER and therefore opt-in (profiles/round5_negative_wgrad_planes.txt): C = 96 k = 3 105.8 us against 104.2 (dilation 9:
+// 115.4 / 103.2), C = 192 82.4 / 75.2, C = 384 89.8 / 67.9, C = 768 95.7 / 70.8, the step 10.13 ms against 9.93 on the same box.  The
+// loop was not conversion-bound: the unaligned fragment reads are inline asm, so each column tile waits for its three
+// fragments with nothing else of the wave in flight (the aligned path's fragment loads are scheduled by the compiler across the
+// MFMA sequence), and the 64-row variants spill 3-10 registers at three workgroups per CU.  What it would take: the reads of
+// column tile 1 / of the next k block issued under the current MFMAs (s_waitcnt lgkmcnt(3)), i.e. six more live fragments.
 template <int TM, int WM, int WN, bool AV, bool PART, bool PL>
 __global__ __launch_bounds__(256, (TM == 2 && WM == 2) ? 3 : 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
@@ -398,11 +404,11 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     const int BM = 32 * pl->tm * pl->wm, BN = 64 * (4 / pl->wm);
     pl->rt = rh_cdiv(w.M, BM);
     pl->ct = rh_cdiv(p->N, BN);
-    // plane mode (round 5): stride-1 layers with several taps whose reach fits the image (<= 7 octets per channel: the
-    // k = 3 units up to dilation 9 -- reach 18 --, the k = 7 stem).  RH_WGRAD_X6_PLANES=0: the per-tap conversion of rounds 2-4.
+    // plane mode (round 5, RH_WGRAD_X6_PLANES=1): stride-1 layers with several taps whose reach fits the image (<= 7 octets
+    // per channel: the k = 3 units up to dilation 9 -- reach 18 --, the k = 7 stem).  Default: the per-tap conversion.
     {
         const char* pe = getenv("RH_WGRAD_X6_PLANES");          // read per call (the tests compare both)
-        const bool on = !(pe && pe[0] == '0');
+        const bool on = pe && pe[0] == '1';                      // OPT-IN: measured slower, see the kernel's header comment
         const int reach = w.maxoff - w.minoff;
         const int p8 = (32 + reach + 7) / 8;
         pl->planes = on && w.is == 1 && w.T >= 2 && reach >= 0 && p8 <= 7 && 4l * (w.s_row + 64) * w.C * w.B < 0x7fffffffl;

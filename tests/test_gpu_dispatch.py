@@ -662,8 +662,9 @@ PLANE_CASES = [
 
 @pytest.mark.parametrize("case", PLANE_CASES, ids=[c[0] for c in PLANE_CASES])
 def test_weight_gradient_with_the_input_staged_once_per_position_is_bit_identical(dev, case):
-    """wgrad_x6_kernel's plane mode (round 5: the input of a stride-1 multi-tap layer converted ONCE per position into bf16
-    element planes, a tap = an unaligned 16-byte LDS read) against the per-tap conversion of rounds 2-4 (RH_WGRAD_X6_PLANES=0):
+    """wgrad_x6_kernel's plane mode (round 5, opt-in RH_WGRAD_X6_PLANES=1 -- measured slower, profiles/round5_negative_wgrad_planes.txt:
+    the input of a stride-1 multi-tap layer converted ONCE per position into bf16 element planes, a tap = an unaligned 16-byte LDS
+    read) against the default per-tap conversion (RH_WGRAD_X6_PLANES=0):
     the same products in the same order -> the weight (and bias) gradients must be the SAME BITS; and against the exact-f32 MFMA
     kernel to 2e-6.  Geometries: every k = 3 / k = 7 layer class of the v2 generator, causal pads, ragged row lengths."""
     from rave_amd import ops as R
