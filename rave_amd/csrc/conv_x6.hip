@@ -118,7 +118,11 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     // (one round of workgroups exposes those loads; the finalize pass streams them) -- hence two thresholds.
     static const int split_env = [] { const char* e = getenv("RH_X6_SPLIT_BELOW"); return e ? atoi(e) : 0; }();
     static const int split_target = [] { const char* e = getenv("RH_X6_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
-    const int split_below = split_env > 0 ? split_env : (p.epi_act != RH_ACT_NONE ? 384 : 200);
+    // (round 5: one threshold.  Rounds 2-4 split launches whose epilogue reads the saved input already below 384 workgroups --
+    // measured per layer, one launch at a time; inside the step, beside the weight-gradient stream, the 256-tile data gradients (the k = 1
+    // convs of the C = 384 units) run faster UNSPLIT: 10.01-10.03 ms per step against 10.05-10.09 in three alternated pairs,
+    // profiles/round5_ab_knobs_and_negative_results.txt)
+    const int split_below = split_env > 0 ? split_env : 200;
     int z = 1;
     if (blocks < split_below) {
         z = rh_cdiv(split_target, blocks);
