@@ -273,10 +273,7 @@ class RAVE(nn.Module):
         z, reg = self.encoder.reparametrize(z, eps)[:2]
 
         y = self.decoder(z)
-        y_multiband = y
-        y_raw = _pqmf_decode(self.pqmf, y, batch_size=batch_size, n_channels=self.n_channels)
-        y_raw = y_raw[..., :x_raw.shape[-1]]
-        y_multiband = y_multiband[..., :x_multiband.shape[-1]]
+        y_multiband = y[..., :x_multiband.shape[-1]]
         if rf[0] + rf[1]:
             y_multiband = valid_signal_crop(y_multiband, rf[0], rf[1])
         x_multiband = x_mb_loss
@@ -284,10 +281,31 @@ class RAVE(nn.Module):
         # the generator loss terms as (value, first factor): on the GPU the products and the weighted sum of
         # rave/model.py:336-344, 392-412 are ONE launch each way (ops.loss_combine, same bits as the ATen chain below)
         terms = {}
-        multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
+        # Round 5: the multiband distance runs BESIDE the PQMF synthesis and the fullband distance, on the stream the
+        # weight-gradient branch uses later in the pass (idle until then; still two streams in the recorded graph).  autograd
+        # runs a node's backward on the stream its forward ran on, so the two distances overlap in both directions: 9.74-9.75 ms
+        # per step against 9.95-10.01 in three alternated pairs (profiles/round5_ab_knobs_and_negative_results.txt); same bits
+        # (no atomics anywhere).  RH_LOSS_SIDE_STREAM=0 / RH_BWD_SIDE_STREAM=0: one stream.
+        import os
+        loss_side = None
+        if batch.is_cuda and os.environ.get("RH_LOSS_SIDE_STREAM", "1") != "0":
+            from . import ops
+            loss_side = ops._side_stream(batch.device) if ops._side_enabled() else None
+        if loss_side is not None:
+            loss_side.wait_stream(torch.cuda.current_stream(batch.device))
+            with torch.cuda.stream(loss_side):
+                multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
+            for t_ in (x_multiband, y_multiband):
+                t_.record_stream(loss_side)
+        else:
+            multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
         for k, v in multiband_distance.items():
             terms[f"multiband_{k}"] = (v, self.weights["multiband_audio_distance"])
+        y_raw = _pqmf_decode(self.pqmf, y, batch_size=batch_size, n_channels=self.n_channels)
+        y_raw = y_raw[..., :x_raw.shape[-1]]
         fullband_distance = self.audio_distance(x_raw, y_raw)
+        if loss_side is not None:
+            torch.cuda.current_stream(batch.device).wait_stream(loss_side)
         for k, v in fullband_distance.items():
             terms[f"fullband_{k}"] = (v, self.weights["audio_distance"])
 
