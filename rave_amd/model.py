@@ -551,6 +551,12 @@ class GraphedTrainingStep:
                 # experiment: record the step on a HIGH-priority stream, so that the data-gradient chain (the critical path)
                 # wins the arbitration against the weight-gradient branch, which forks onto a default-priority stream
                 kw["stream"] = torch.cuda.Stream(priority=-1)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # RCCL's watchdog thread polls the events of earlier collectives (hipEventQuery) whenever it likes; under the
+                # default capture_error_mode = "global" such a call from ANOTHER thread while this one records is an error, which
+                # the watchdog turns into an abort of the process (ProcessGroupNCCL.cpp: Watchdog::run) -- intermittently, about
+                # one data-parallel capture in four on these boxes (round 5).  "thread_local" restricts the check to this thread.
+                kw["capture_error_mode"] = "thread_local"
             with torch.cuda.graph(g, **kw):
                 if self.before_step is not None:
                     self.before_step()
