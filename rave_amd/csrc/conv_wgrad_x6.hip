@@ -97,10 +97,11 @@ constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
 // 115.4 / 103.2), C = 192 82.4 / 75.2, C = 384 89.8 / 67.9, C = 768 95.7 / 70.8, the step 10.13 ms against 9.93 on the same box.  The
 // loop was not conversion-bound: the unaligned fragment reads are inline asm, so each column tile waits for its three
 // fragments with nothing else of the wave in flight (the aligned path's fragment loads are scheduled by the compiler across the
-// MFMA sequence), and the 64-row variants spill 3-10 registers at three workgroups per CU.  What it would take: the reads of
+// MFMA sequence), and the 64-row variants need 170-190 registers: two workgroups per CU instead of three (forced under 168 they
+// spill 3-10).  What it would take: the reads of
 // column tile 1 / of the next k block issued under the current MFMAs (s_waitcnt lgkmcnt(3)), i.e. six more live fragments.
 template <int TM, int WM, int WN, bool AV, bool PART, bool PL>
-__global__ __launch_bounds__(256, (TM == 2 && WM == 2) ? 3 : 2) void wgrad_x6_kernel(const Wx6P p) {
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 64 * WN;
     // fragments of ONE k block: [g][piece][rows], with 4 fragments of padding per g block.  The OCT = 4 lanes that convert
