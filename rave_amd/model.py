@@ -510,7 +510,14 @@ class GraphedTrainingStep:
         m = self.model
         return bool(m.warmed_up) and not (batch_idx % m.update_discriminator_every)
 
-    def __call__(self, batch: torch.Tensor, batch_idx: int, eps: Optional[torch.Tensor] = None):
+    def capture(self, batch: torch.Tensor, batch_idx: int, eps: Optional[torch.Tensor] = None) -> None:
+        """Records the graph of this (phase, step kind) WITHOUT replaying it: the warm-up iterations run (and are rolled back),
+        the capture executes nothing.  Data-parallel callers use it to agree across ranks that every rank recorded its step
+        before any rank replays one -- a rank that replays while another fell back to the eager step would wait in a
+        collective nobody else enters."""
+        self(batch, batch_idx, eps, _replay=False)
+
+    def __call__(self, batch: torch.Tensor, batch_idx: int, eps: Optional[torch.Tensor] = None, _replay: bool = True):
         m = self.model
         key = (bool(m.warmed_up), self._key(batch_idx))
         with torch.no_grad():            # (training_step marks its input as requiring grad, rave/model.py:292)
@@ -564,6 +571,8 @@ class GraphedTrainingStep:
             # the capture itself does not execute anything: parameters are still the restored ones
             self.graphs[key] = (g, logged)
         g, logged = self.graphs[key]
+        if not _replay:
+            return logged
         m.beta_device(self.x.device)     # per-step scalar the recorded step reads from device memory
         g.replay()
         if m._prep is not None:          # the replayed optimizer changed parameters behind the version counters

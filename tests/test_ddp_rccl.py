@@ -96,19 +96,26 @@ def _worker(rank, world, port, outdir):
 
     # ---- the same two steps as hipGraph replays with the collectives inside the graph
     m, gen, red, sync = fresh(True)
+    graphed = None
     try:
         graphed = M.GraphedTrainingStep(m, xs, inject_eps=True, grad_begin=lambda idx: red.begin(),
                                         grad_sync=lambda idx: red.finish(), before_step=sync.sync)
+        graphed.capture(xs, 0, eps=es)          # records, replays nothing
+        torch.cuda.synchronize()
+        out["graph"] = "captured"
+    except Exception as e:              # noqa: BLE001 -- the outcome is REPORTED and asserted on by the parent
+        out["graph"] = f"eager fallback: {type(e).__name__}: {str(e)[:300]}"
+    # every rank must have recorded its step before any rank replays one (a replay enters collectives)
+    ok = torch.tensor([1 if out["graph"] == "captured" else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    out["graph_all_ranks"] = int(ok.item())
+    if out["graph_all_ranks"]:
         for it in range(2):
             graphed(xs, 0, eps=es)
         torch.cuda.synchronize()
-        out["graph"] = "captured"
         out["graph_params"] = {k: p.detach().cpu().clone() for k, p in m.named_parameters()}
-    except Exception as e:              # noqa: BLE001 -- the outcome is REPORTED and asserted on by the parent
-        out["graph"] = f"eager fallback: {type(e).__name__}: {str(e)[:300]}"
-    ok = torch.tensor([1 if out["graph"] == "captured" else 0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # (a rank must not wait in a collective the other never enters)
-    out["graph_all_ranks"] = int(ok.item())
+    elif out["graph"] == "captured":
+        out["graph"] = "eager fallback: the other rank could not record its step"
     torch.save(out, os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -153,7 +160,7 @@ def test_two_ranks_over_rccl_average_overlap_and_capture(tmp_path):
     print("data-parallel hipGraph capture over RCCL:", [o["graph"] for o in outs])
     for o in outs:
         assert o["graph"] == "captured" or o["graph"].startswith("eager fallback: "), o["graph"]
-    if all(o["graph"] == "captured" for o in outs):
+    if all(o["graph"] == "captured" and o["graph_all_ranks"] for o in outs):
         for k in outs[0]["graph_params"]:
             assert torch.equal(outs[0]["graph_params"][k], outs[1]["graph_params"][k]), k
             assert torch.equal(outs[0]["graph_params"][k], outs[0]["eager_params"][k]), k
