@@ -203,19 +203,33 @@ def run_conv2d_layer(layer, x):
     return layer(x)
 
 
+# The Encodec spectral net IS its layer table -- kernel, stride, dilation per block (rave/discriminator.py:57-66; the drop-in contract
+# is "same module tree, same state_dict keys", so the table is necessarily the reference's): (9,3) stem on the (real, imag)
+# planes, three (9,3) blocks striding 2 along frequency with time dilation 1 / 2 / 4, a (3,3) block and the (3,3) scoring conv.
+ENCODEC_BLOCKS = (
+    # kernel, stride,  dilation, role
+    ((9, 3), None,     None,     "stem"),
+    ((9, 3), (2, 1),   (1, 1),   "body"),
+    ((9, 3), (2, 1),   (1, 2),   "body"),
+    ((9, 3), (2, 1),   (1, 4),   "body"),
+    ((3, 3), None,     None,     "body"),
+    ((3, 3), None,     None,     "score"),
+)
+
+
 class EncodecConvNet(nn.Module):
-    """rave/discriminator.py:54-74."""
+    """rave/discriminator.py:54-74: the blocks of ENCODEC_BLOCKS in ``net`` (indices = the reference's state_dict keys); forward
+    returns every block's output (post-activation for all but the scoring conv), each block one HIP conv launch with its
+    LeakyReLU in the epilogue (run_conv2d_layer)."""
 
     def __init__(self, capacity: int, n_channels: int = 1) -> None:
         super().__init__()
-        self.net = nn.Sequential(
-            rectified_2d_conv_block(capacity, (9, 3), in_size=2 * n_channels),
-            rectified_2d_conv_block(capacity, (9, 3), (2, 1), (1, 1)),
-            rectified_2d_conv_block(capacity, (9, 3), (2, 1), (1, 2)),
-            rectified_2d_conv_block(capacity, (9, 3), (2, 1), (1, 4)),
-            rectified_2d_conv_block(capacity, (3, 3)),
-            rectified_2d_conv_block(capacity, (3, 3), out_size=1, activation=False),
-        )
+        blocks = []
+        for kernel, stride, dilation, role in ENCODEC_BLOCKS:
+            blocks.append(rectified_2d_conv_block(capacity, kernel, stride, dilation,
+                                                  in_size=2 * n_channels if role == "stem" else None,
+                                                  out_size=1 if role == "score" else None, activation=role != "score"))
+        self.net = nn.Sequential(*blocks)
 
     def forward(self, x):
         features = []
