@@ -691,17 +691,20 @@ def test_v1_generator_side_golden(golden_dir, dev):
         assert rel_l2(named[k].grad, gref) < 2e-4, (k, rel_l2(named[k].grad, gref))
 
 
-def test_v2_full_size_forward_vs_oracle(dev):
-    """BASELINE config 2 geometry (v2, CAPACITY 96, 65536 samples), batch 2: PQMF -> EncoderV2 ->
-    reparametrize -> GeneratorV2 -> PQMF^-1 on the GPU vs the CPU oracle; <= 1e-4 relative L2."""
+@pytest.mark.parametrize("batch", [2, 32])
+def test_v2_full_size_forward_vs_oracle(dev, batch):
+    """BASELINE configs[1] geometry (v2, CAPACITY 96, 65536 samples): PQMF -> EncoderV2 -> reparametrize -> GeneratorV2 ->
+    PQMF^-1 on the GPU vs the CPU oracle; <= 1e-4 relative L2.  batch 32 = the BENCHMARKED dispatch (other tile shapes, K
+    splits and batch folding than batch 2: tests/test_gpu_dispatch.py) against the oracle itself, not only against the
+    exact-f32 kernels ("batch-32 correctness is a self-comparison")."""
     from rave_amd import model as M
     cfg = O.v2_config()
     sd = O.init_state_dict(cfg, seed=0, with_discriminator=False)
     m = M.build_v2()
     m.load_state_dict(sd, strict=False)
     m = m.to(dev).train()
-    x = O.synthetic_batch(2, 1, 65536)
-    eps = torch.randn(2, 128, 32, generator=torch.Generator().manual_seed(1))
+    x = O.synthetic_batch(batch, 1, 65536)
+    eps = torch.randn(batch, 128, 32, generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         ref = O.rave_forward(x, sd, cfg, eps)
         zp, x_mb = m.encode(x.to(dev), return_mb=True)
