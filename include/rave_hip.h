@@ -167,6 +167,26 @@ int rh_residual_unit_fused(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1); 
 int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1, const float* x, const float* wp3_fwd,
                              const float* wp1_fwd, float* h, float* y, rh_stream_t stream);
 
+/* ---- range slots of the f16 matrix-core kernels (round 6) ---------------------------------------------------------------
+ * The "x6" kernels (conv_x6_kernel, unit_x6_kernel, wgrad_x6_kernel) compute exact-f32-class products on the f16 matrix cores:
+ * every operand is scaled by a power of two that takes its TENSOR's largest magnitude into [2^14, 2^15) and split into two
+ * f16 pieces (csrc/common.hpp).  The scale needs max |x| of each activation operand; it travels in a RANGE SLOT: an array of
+ * rh_x6_range_words() uint32 in device memory, each the bit pattern of a non-negative float -- max |x| is the largest word (any
+ * upper bound within a factor of ~2^10 of it keeps f32 accuracy; a too SMALL value overflows f16: the slot must cover the
+ * tensor).  rh_x6_set_ranges arms the slots of the NEXT rh_conv1d_fwd_f32 / rh_conv1d_bwd_data_f32 / rh_residual_unit_fwd_f32
+ * / rh_conv1d_bwd_weight[_wn]_f32 call of this thread (consumed by that call, like rh_set_kernel_events):
+ *     in_a   weight gradient only: the slot of dy          in_b   the slot of the input activation (x; dy for bwd_data)
+ *     out    where the call leaves max |output| (forward: y, bwd_data: dx; atomicMax, the caller zeroes it first) or NULL
+ *     out2   rh_residual_unit_fwd_f32: the slot of the intermediate h, or NULL
+ * A call whose input slot is NULL takes the f32-input MFMA kernels instead (same results to f32 rounding, slower).
+ * rh_amax_f32 fills a (zeroed) slot from a tensor no kernel of this library produced.  rh_x6_uses_ranges() = 1 for this
+ * build (0 = the bf16 x 6 comparison build, which ignores slots).  The weights' own range is recorded by the pack kernels
+ * inside the packed operand.  Reference sites: every conv of rave/blocks.py:83-112,514-714 and rave/discriminator.py:77-119. */
+int rh_x6_uses_ranges(void);
+int rh_x6_range_words(void);
+int rh_x6_set_ranges(const uint32_t* in_a, const uint32_t* in_b, uint32_t* out, uint32_t* out2);
+int rh_amax_f32(const float* x, int64_t n, uint32_t* slot, rh_stream_t stream);
+
 /* Diagnostics: out8 = {family, row tiles per wave, column tiles per wave, waves along the rows, K slices, input stride of the
  * fragment layout, virtual rows, workgroups} of the launch rh_conv1d_fwd_f32 (which = 0) / rh_conv1d_bwd_data_f32
  * (which = 1) would issue; zeros behind `family` for the non-bf16x6 families.  Lets the parity tests assert that the

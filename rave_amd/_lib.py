@@ -133,6 +133,10 @@ def _load() -> C.CDLL:
         "rh_loss_combine_fwd_f32": ([C.POINTER(LossItem), I32, P, P, P], C.c_int),
         "rh_loss_combine_bwd_f32": ([C.POINTER(LossItem), I32, P, P, P], C.c_int),
         "rh_adam_step_f32": ([C.POINTER(AdamItem), I32, P, F, F, F, P, P], C.c_int),
+        "rh_x6_uses_ranges": ([], C.c_int),
+        "rh_x6_range_words": ([], C.c_int),
+        "rh_x6_set_ranges": ([P, P, P, P], C.c_int),
+        "rh_amax_f32": ([P, I64, P, P], C.c_int),
         "rh_set_kernel_events": ([P, P], C.c_int),
         "rh_kernel_events_used": ([], C.c_int),
         "rh_event_create": ([C.POINTER(C.c_void_p)], C.c_int),

@@ -40,6 +40,26 @@ extern "C" int rh_kernel_events_used(void) {
     return u;
 }
 
+// Range slots of the NEXT convolution / residual-unit / weight-gradient call of this thread (common.hpp: RH_X6_F16).
+thread_local const unsigned* rh_rng_a = nullptr;
+thread_local const unsigned* rh_rng_b = nullptr;
+thread_local unsigned* rh_rng_out = nullptr;
+thread_local unsigned* rh_rng_out2 = nullptr;
+extern "C" int rh_x6_set_ranges(const uint32_t* a, const uint32_t* b, uint32_t* out, uint32_t* out2) {
+    rh_rng_a = a; rh_rng_b = b; rh_rng_out = out; rh_rng_out2 = out2;
+    return RH_OK;
+}
+void rh_take_ranges(const unsigned** a, const unsigned** b, unsigned** out, unsigned** out2) {
+    if (a) *a = rh_rng_a;
+    if (b) *b = rh_rng_b;
+    if (out) *out = rh_rng_out;
+    if (out2) *out2 = rh_rng_out2;
+    rh_rng_a = rh_rng_b = nullptr;
+    rh_rng_out = rh_rng_out2 = nullptr;
+}
+extern "C" int rh_x6_uses_ranges(void) { return RH_X6_F16 ? 1 : 0; }
+extern "C" int rh_x6_range_words(void) { return kRangeWords; }
+
 extern "C" int rh_event_create(void** ev) {
     RH_REQUIRE(ev, RH_ERR_INVALID, "event_create: null pointer");
     hipEvent_t e;

@@ -1147,6 +1147,7 @@ int fill_pack2(const rh_conv2d_desc* d, int which, const float* w, float* wp, Pa
     if (units > 0 && units * 4 < 0x7fffffffl) {
         p->wq = reinterpret_cast<unsigned*>(wp + p->total);
         p->x6_mode = 1;
+        p->bf16x3 = 1;             // this operand keeps three bf16 pieces in every build (conv_params.hpp)
         for (int ph = 0; ph < t.nphase; ++ph)
             for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
                 p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 6 * p->Mp);

@@ -29,6 +29,11 @@
 
 namespace {
 
+// This kernel keeps the three-piece bf16 scheme in every build (its operand is packed by conv2d.hip, without range records).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define RH_C2X_SA {2, 0, 1, 1, 0, 0}
+#define RH_C2X_SB {0, 2, 1, 0, 1, 0}
+
 template <int TM, int TN, int NQ>
 __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
     constexpr int BM = 32 * TM;
@@ -128,9 +133,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
             if (xdst[q] < 0) continue;
             unsigned h[3][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rh_x6_split(xr[q][i], h[0][i], h[1][i], h[2][i]);
+            for (int i = 0; i < 8; ++i) rh_bf3_split(xr[q][i], h[0][i], h[1][i], h[2][i]);
 #pragma unroll
-            for (int s3 = 0; s3 < RH_X6_NPIECE; ++s3) {
+            for (int s3 = 0; s3 < 3; ++s3) {
                 u32x4 pk;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pk[k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
                 store_a((st + 1) & 1);
                 if (st + 2 < S) load_a(st + 2);
             }
-            constexpr int SA[RH_X6_NPROD] = RH_X6_SA, SB[RH_X6_NPROD] = RH_X6_SB;     // smallest terms first
+            constexpr int SA[6] = RH_C2X_SA, SB[6] = RH_C2X_SB;     // smallest terms first
 #pragma unroll
-            for (int q = 0; q < RH_X6_NPROD; ++q)
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -227,7 +232,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
     const auto none_r = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(nullptr), 0, 0, 0x00020000);
     const bool full = m0 + BM <= p.M;
     const int mode = (p.bias ? 1 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
-#define RH_C2X_ROWS(MODE) x6_store_tile<MODE, TM, TN>(acc, cb, m0, g, p.M, full, oplane, out_r, none_r, none_r, bias_r, 1.f, p.out_slope)
+    float amax_unused = 0.f;
+#define RH_C2X_ROWS(MODE) x6_store_tile<MODE, TM, TN>(acc, cb, m0, g, p.M, full, oplane, out_r, none_r, none_r, bias_r, 1.f, p.out_slope, 1.f, amax_unused)
     if (mode == 0) RH_C2X_ROWS(0);
     else if (mode == 1) RH_C2X_ROWS(1);
     else if (mode == 8) RH_C2X_ROWS(8);

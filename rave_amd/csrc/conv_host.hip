@@ -182,17 +182,17 @@ long x6_units(const TapPlan& t, int mode, long* ph_ofs = nullptr, int inner = 1,
         long u = 0;
         for (int ph = 0; ph < t.nphase; ++ph) {
             if (ph_ofs) ph_ofs[ph] = u;
-            u += (long)(t.C >> 4) * t.ntaps[ph] * 6 * Mp;
+            u += (long)(t.C >> 4) * t.ntaps[ph] * 2 * kX6P * Mp;
         }
         VPlan v;
         if (vplan_of(t, inner, &v)) {
             if (vofs) *vofs = u;
-            u += (long)(t.C >> 4) * v.U * 6 * round32(t.M * v.s);
+            u += (long)(t.C >> 4) * v.U * 2 * kX6P * round32(t.M * v.s);
         }
         return u;
     }
     if (ph_ofs) ph_ofs[0] = 0;
-    return (long)((t.C * mode) >> 4) * rh_cdiv(t.ntaps[0], mode) * 6 * Mp;
+    return (long)((t.C * mode) >> 4) * rh_cdiv(t.ntaps[0], mode) * 2 * kX6P * Mp;
 }
 void plan_to_x6(const TapPlan& t, int inner, ConvP* p) {
     p->x6_mode = x6_mode_of(t, inner);
@@ -219,20 +219,20 @@ void plan_to_x6(const TapPlan& t, int inner, ConvP* p) {
 // walks them ([phase][step][g][piece][Mp], layouts in conv_params.hpp).
 constexpr int kPackSlots = 4;      // slots per pass: 16.9 KB of LDS (8 slots: 385 us for the v2 model's repack, 4: 314)
 
-__device__ __forceinline__ void split3_bits(float x, unsigned& a, unsigned& b, unsigned& c) {
-    rh_x6_split(x, a, b, c);          // (common.hpp: exact 3-way split; 2 pieces in the RH_X6_PRODUCTS measurement builds)
-    a &= 0xffff0000u; b &= 0xffff0000u; c &= 0xffff0000u;
-}
-
 __host__ __device__ __forceinline__ long pack_tiles(const PackP& q) {
     return q.total ? (long)(q.Mp / 32) * ((q.C + 31) / 32) : 0;
 }
 
-__device__ __forceinline__ void emit_fragment(const float (&v)[8], unsigned* dst, long piece_stride_u32) {
+// The kX6P pieces of 8 K values as 16-byte fragments.  f16 build: the values are scaled by `sc` (the power of two that takes
+// the tensor's max |w| into [2^14, 2^15): common.hpp) and split hi / lo; bf16 build: exact 3-way truncation split, sc unused.
+__device__ __forceinline__ void emit_fragment_bf3(const float (&v)[8], unsigned* dst, long piece_stride_u32) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned h[3][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split3_bits(v[i], h[0][i], h[1][i], h[2][i]);
+    for (int i = 0; i < 8; ++i) {
+        rh_bf3_split(v[i], h[0][i], h[1][i], h[2][i]);
+        h[0][i] &= 0xffff0000u; h[1][i] &= 0xffff0000u; h[2][i] &= 0xffff0000u;
+    }
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
         u32x4 pk;
@@ -240,6 +240,33 @@ __device__ __forceinline__ void emit_fragment(const float (&v)[8], unsigned* dst
         for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
         *reinterpret_cast<u32x4*>(dst + s3 * piece_stride_u32) = pk;
     }
+}
+__device__ __forceinline__ void emit_fragment(const float (&v)[8], unsigned* dst, long piece_stride_u32, float sc) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#if RH_X6_F16
+    u32x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const rh_h2 h = rh_h2_split(v[2 * k] * sc, v[2 * k + 1] * sc);
+        hi[k] = h.hi; lo[k] = h.lo;
+    }
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + piece_stride_u32) = lo;
+#else
+    unsigned h[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        rh_bf3_split(v[i], h[0][i], h[1][i], h[2][i]);
+        h[0][i] &= 0xffff0000u; h[1][i] &= 0xffff0000u; h[2][i] &= 0xffff0000u;
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        u32x4 pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = (h[s3][2 * k] >> 16) | h[s3][2 * k + 1];
+        *reinterpret_cast<u32x4*>(dst + s3 * piece_stride_u32) = pk;
+    }
+#endif
 }
 
 // (sg, sn): this workgroup takes the slot groups sg, sg + sn, ... of the tile -- a conv with ONE 32 x 32 tile and 27 taps
@@ -250,6 +277,13 @@ __device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds 
     const int c0 = (int)(tile % ct) * 32;
     const int m0 = (int)(tile / ct) * 32;
     const int tid = threadIdx.x;
+    float fsc = 1.f;              // f16 build: scale of the pieces, from the range record the range kernel left behind the fragments
+#if RH_X6_F16
+    if (q.wq && !q.bf16x3) {
+        int inv;
+        fsc = __uint_as_float(rh_x6_scale_bits(q.range[0], &inv));
+    }
+#endif
     for (int s0 = sg * kPackSlots; s0 < q.nslots; s0 += sn * kPackSlots) {
         const int ns = min(kPackSlots, q.nslots - s0);
         // U elements per thread are LOADED before the first one is stored: one element per iteration (index -> tap table ->
@@ -302,8 +336,13 @@ __device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = lds[(sl * 32 + oct * 8 + i) * 33 + ml];
                 const int slot = s0 + sl;
-                const long unit = (long)q.q2a[slot] + (long)(cb >> 4) * q.q2n[slot] + (long)(((cb >> 3) & 1) * 3) * q.Mp + m0 + ml;
-                emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4);
+                if (q.bf16x3) {          // (the 2-D kernels' operand: q2a / q2n were filled for three pieces)
+                    const long unit3 = (long)q.q2a[slot] + (long)(cb >> 4) * q.q2n[slot] + (long)(((cb >> 3) & 1) * 3) * q.Mp + m0 + ml;
+                    emit_fragment_bf3(v, q.wq + unit3 * 4, (long)q.Mp * 4);
+                    continue;
+                }
+                const long unit = (long)q.q2a[slot] + (long)(cb >> 4) * q.q2n[slot] + (long)(((cb >> 3) & 1) * kX6P) * q.Mp + m0 + ml;
+                emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4, fsc);
             }
         }
         if (q.wq && q.x6_vs > 1) {         // second section: virtual rows
@@ -317,8 +356,8 @@ __device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = lds[(sl * 32 + oct * 8 + i) * 33 + ml];
                 const int slot = s0 + sl;
-                const long unit = q.x6_vofs + q.vq2a[slot] + (long)(cb >> 4) * q.x6_U * 6 * q.x6_Mvp + (long)(((cb >> 3) & 1) * 3) * q.x6_Mvp + r;
-                emit_fragment(v, q.wq + unit * 4, (long)q.x6_Mvp * 4);
+                const long unit = q.x6_vofs + q.vq2a[slot] + (long)(cb >> 4) * q.x6_U * 2 * kX6P * q.x6_Mvp + (long)(((cb >> 3) & 1) * kX6P) * q.x6_Mvp + r;
+                emit_fragment(v, q.wq + unit * 4, (long)q.x6_Mvp * 4, fsc);
             }
             if (s0 == 0) {         // (row group j, tap u) pairs no slot covers: phases with fewer taps than the longest
                 const float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -327,9 +366,9 @@ __device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds 
                     const int cb = c0 + oct * 8;
                     const int r = (m0 + ml) * vs + q.vz_j[zi];
                     if (cb >= q.C || r >= q.x6_Mvp) continue;
-                    const long unit = q.x6_vofs + (long)q.vz_u[zi] * 6 * q.x6_Mvp + (long)(cb >> 4) * q.x6_U * 6 * q.x6_Mvp +
-                                      (long)(((cb >> 3) & 1) * 3) * q.x6_Mvp + r;
-                    emit_fragment(zero, q.wq + unit * 4, (long)q.x6_Mvp * 4);
+                    const long unit = q.x6_vofs + (long)q.vz_u[zi] * 2 * kX6P * q.x6_Mvp + (long)(cb >> 4) * q.x6_U * 2 * kX6P * q.x6_Mvp +
+                                      (long)(((cb >> 3) & 1) * kX6P) * q.x6_Mvp + r;
+                    emit_fragment(zero, q.wq + unit * 4, (long)q.x6_Mvp * 4, fsc);
                 }
             }
         }
@@ -349,8 +388,8 @@ __device__ __forceinline__ void pack_tile(const PackP& q, long tile, float* lds 
                     const int cl = cv * cpc + kap / IS, sl = ul * IS + kap % IS;
                     v[i] = sl < ns ? lds[(sl * 32 + cl) * 33 + ml] : 0.f;
                 }
-                const long unit = ((long)(cbase / cpc) * q.x6_nu + (s0 / IS + ul)) * 6 * q.Mp + (long)(g * 3) * q.Mp + m0 + ml;
-                emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4);
+                const long unit = ((long)(cbase / cpc) * q.x6_nu + (s0 / IS + ul)) * 2 * kX6P * q.Mp + (long)(g * kX6P) * q.Mp + m0 + ml;
+                emit_fragment(v, q.wq + unit * 4, (long)q.Mp * 4, fsc);
             }
         }
         __syncthreads();
@@ -393,6 +432,7 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
     const long units = x6_units(t, mode, ph_ofs, d->inner, &vofs);
     if (mode && units * 4 < 0x7fffffffl) {
         p->wq = reinterpret_cast<unsigned*>(wp + p->total);            // 16-byte aligned: Mp % 32 == 0
+        p->range = p->wq + units * 4;                                  // {max |w|, max row sum |w|, 0, 0} behind the fragments
         p->x6_mode = mode;
         if (vofs >= 0) {
             VPlan v;
@@ -405,7 +445,7 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
             for (int ph = 0; ph < t.nphase; ++ph)
                 for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
                     const int slot = t.tap0[ph] + tl;
-                    p->vq2a[slot] = tl * 6 * p->x6_Mvp;
+                    p->vq2a[slot] = tl * 2 * kX6P * p->x6_Mvp;
                     p->q2j[slot] = v.jof[ph];
                     have[v.jof[ph]][tl] = true;
                 }
@@ -419,14 +459,38 @@ int fill_pack(const rh_conv1d_desc* d, int which, const float* w, const float* s
         if (mode == 1) {
             for (int ph = 0; ph < t.nphase; ++ph)
                 for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
-                    p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 6 * p->Mp);
-                    p->q2n[t.tap0[ph] + tl] = t.ntaps[ph] * 6 * p->Mp;
+                    p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 2 * kX6P * p->Mp);
+                    p->q2n[t.tap0[ph] + tl] = t.ntaps[ph] * 2 * kX6P * p->Mp;
                 }
         } else {
             p->x6_nu = rh_cdiv(t.ntaps[0], mode);
         }
     }
     return RH_OK;
+}
+
+// Range record of a weight tensor (rows = dim 0, cols = the rest; scale = the weight-norm factor per row or null): max |w| and
+// the largest row sum of |w| (for Conv1d a row of dim 0 is a GEMM row of the forward operand: |conv(x, w)| <= max |x| times it --
+// the bound unit_x6.hip scales its intermediate with), as float bit patterns atomicMax'ed into the (zeroed) records of both
+// packed copies.  One workgroup per row.  max |scale * v| == |scale| * max |v| bit for bit (rounding is monotonic).
+__global__ __launch_bounds__(256) void pack_range_kernel(const float* __restrict__ w, const float* __restrict__ scale, long cols,
+                                                         unsigned* ra, unsigned* rb) {
+    __shared__ float red[8];
+    const long r = blockIdx.x;
+    const float* wr = w + r * cols;
+    float mx = 0.f, sm = 0.f;
+    for (long e = threadIdx.x; e < cols; e += 256) { const float a = fabsf(wr[e]); mx = fmaxf(mx, a); sm += a; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); sm += __shfl_down(sm, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; red[4 + (threadIdx.x >> 6)] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sc = scale ? fabsf(scale[r]) : 1.f;
+        const float m = sc * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float l1 = sc * ((red[4] + red[5]) + (red[6] + red[7]));
+        if (ra) { atomicMax(ra, __float_as_uint(m)); atomicMax(ra + 1, __float_as_uint(l1)); }
+        if (rb) { atomicMax(rb, __float_as_uint(m)); atomicMax(rb + 1, __float_as_uint(l1)); }
+    }
 }
 
 int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float* wp_fwd, float* wp_bwd,
@@ -436,6 +500,14 @@ int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float
     if (int e = fill_pack(d, 1, w, scale, wp_bwd, &b)) return e;
     const long tiles = pack_tiles(a) + pack_tiles(b);
     if (tiles == 0) return RH_OK;
+    if (a.range || b.range) {
+        if (a.range && hipMemsetAsync(a.range, 0, 16, stream) != hipSuccess) return rh_check_launch("conv1d_pack_range");
+        if (b.range && hipMemsetAsync(b.range, 0, 16, stream) != hipSuccess) return rh_check_launch("conv1d_pack_range");
+        const long rows = d->transposed ? d->c_in : d->c_out;
+        const long cols = (long)(d->transposed ? d->c_out : d->c_in) * d->kernel;
+        hipLaunchKernelGGL(pack_range_kernel, dim3((unsigned)rows), dim3(256), 0, stream, w, scale, cols, a.range, b.range);
+        if (int e = rh_check_launch("conv1d_pack_range")) return e;
+    }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles, pack_slot_groups(a, b, tiles)), dim3(256), 0, stream, a, b);
     return rh_check_launch("conv1d_pack");
 }
@@ -504,7 +576,7 @@ extern "C" int64_t rh_conv1d_packed_floats(const rh_conv1d_desc* d, int which) {
     if (build_plan(d, which, &t)) return -1;
     // + the bf16x6 section (3 x 2 bytes per K value, K padded to whole steps) for the geometries conv_x6.hip takes
     const long units = x6_units(t, x6_mode_of(t, d->inner), nullptr, d->inner);
-    return units * 4 < 0x7fffffffl ? n32 + units * 4 : n32;
+    return (units > 0 && units * 4 < 0x7fffffffl) ? n32 + units * 4 + 4 : n32;      // (+ the range record)
 }
 
 extern "C" int rh_conv1d_pack_f32(const rh_conv1d_desc* d, const float* w, float* wp_fwd,
@@ -542,22 +614,44 @@ __device__ __forceinline__ int find_item(const PrepItem* items, int n, long key,
     return lo;
 }
 
+__global__ __launch_bounds__(256) void prep_clear_kernel(const PrepItem* __restrict__ items, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * n) return;
+    unsigned* r = (i & 1) ? items[i >> 1].bwd.range : items[i >> 1].fwd.range;
+    if (r) { r[0] = 0u; r[1] = 0u; r[2] = 0u; r[3] = 0u; }
+}
+
 __global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __restrict__ items, int n) {
-    __shared__ float red[4];
+    __shared__ float red[12];
     const int it = find_item(items, n, blockIdx.x, true);
     const PrepItem& p = items[it];
     const long r = (long)blockIdx.x - p.row_begin;
     const float* vr = p.v + r * p.cols;
-    float s = 0.f;
-    for (long e = threadIdx.x; e < p.cols; e += 256) { const float a = vr[e]; s += a * a; }
+    float s = 0.f, mx = 0.f, sm = 0.f;
+    for (long e = threadIdx.x; e < p.cols; e += 256) {
+        const float a = vr[e];
+        s += a * a;
+        mx = fmaxf(mx, fabsf(a));
+        sm += fabsf(a);
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        sm += __shfl_down(sm, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = mx; red[8 + (threadIdx.x >> 6)] = sm; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+        const float sc = p.g[r] / norm;
         p.norms[r] = norm;
-        p.scale[r] = p.g[r] / norm;
+        p.scale[r] = sc;
+        // range record of the layer (pack_range_kernel's arithmetic): read by prep_pack_kernel and by the f16 conv kernels
+        const float m = fabsf(sc) * fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        const float l1 = fabsf(sc) * ((red[8] + red[9]) + (red[10] + red[11]));
+        if (p.fwd.range) { atomicMax(p.fwd.range, __float_as_uint(m)); atomicMax(p.fwd.range + 1, __float_as_uint(l1)); }
+        if (p.bwd.range) { atomicMax(p.bwd.range, __float_as_uint(m)); atomicMax(p.bwd.range + 1, __float_as_uint(l1)); }
     }
 }
 
@@ -610,6 +704,9 @@ extern "C" int rh_prep_run_f32(const void* items_dev, int32_t n, int64_t total_r
                                rh_stream_t stream) {
     RH_REQUIRE(items_dev && n > 0, RH_ERR_INVALID, "prep_run: bad arguments");
     if (total_rows > 0) {
+        hipLaunchKernelGGL(prep_clear_kernel, dim3((unsigned)rh_cdiv(2 * n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const PrepItem*)items_dev, n);
+        if (int e = rh_check_launch("prep_clear")) return e;
         hipLaunchKernelGGL(prep_scales_kernel, dim3((unsigned)total_rows), dim3(256), 0, (hipStream_t)stream,
                            (const PrepItem*)items_dev, n);
         if (int e = rh_check_launch("prep_scales")) return e;
@@ -684,11 +781,19 @@ extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const 
                                  const float* bias, const float* snake_alpha, const float* residual,
                                  float* y, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
     ConvP p{};
+    rh_take_ranges(nullptr, &p.in_range, &p.out_range, nullptr);       // consumed by this call whatever happens below
+    const unsigned* const in_range = p.in_range;
+    unsigned* const out_range = p.out_range;
     if (int e = rh_conv_fill_fwd(d, &p)) return e;
+    p.in_range = in_range; p.out_range = out_range;
     if (d->batch == 0 || d->l_out == 0) return RH_OK;
     RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv1d_fwd: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
-    if (rh_smallc_fwd_eligible(d, residual != nullptr)) return rh_smallc_fwd(d, x, wp_fwd, bias, y, (hipStream_t)stream);
+    if (rh_smallc_fwd_eligible(d, residual != nullptr)) {
+        if (int e = rh_smallc_fwd(d, x, wp_fwd, bias, y, (hipStream_t)stream)) return e;
+        p.out = y;
+        return rh_range_after(p, (hipStream_t)stream);
+    }
     p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
     p.wq = reinterpret_cast<const unsigned*>(wp_fwd + p.x6_wofs);
     p.in_alpha = snake_alpha; p.mul_alpha = nullptr;
@@ -701,7 +806,11 @@ extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, 
                                       float* dx, void* workspace, int64_t workspace_bytes,
                                       rh_stream_t stream) {
     ConvP p{};
+    rh_take_ranges(nullptr, &p.in_range, &p.out_range, nullptr);
+    const unsigned* const in_range = p.in_range;
+    unsigned* const out_range = p.out_range;
     if (int e = rh_conv_fill_dgrad(d, &p)) return e;
+    p.in_range = in_range; p.out_range = out_range;
     if (d->batch == 0 || d->l_in == 0) return RH_OK;
     RH_REQUIRE(dy && wp_bwd && dx, RH_ERR_INVALID, "conv1d_bwd_data: null pointer");
     RH_REQUIRE(d->act == RH_ACT_NONE || x, RH_ERR_INVALID, "conv1d_bwd_data: act needs the forward input");
@@ -711,7 +820,9 @@ extern "C" int rh_conv1d_bwd_data_f32(const rh_conv1d_desc* d, const float* dy, 
         if (int e = build_plan(d, 1, &t)) return e;
         int slot_of_tap[kMaxTaps];
         for (int i = 0; i < t.nslots; ++i) slot_of_tap[t.kk[i]] = i;
-        return rh_smallc_dgrad(d, dy, wp_bwd, slot_of_tap, dx, (hipStream_t)stream);
+        if (int e = rh_smallc_dgrad(d, dy, wp_bwd, slot_of_tap, dx, (hipStream_t)stream)) return e;
+        p.out = dx;
+        return rh_range_after(p, (hipStream_t)stream);
     }
     p.in = dy; p.wp = wp_bwd; p.out = dx; p.bias = nullptr; p.add = add;
     p.wq = reinterpret_cast<const unsigned*>(wp_bwd + p.x6_wofs);

@@ -220,8 +220,17 @@ int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what, void* ws, int
 
 int rh_conv_launch_sync(ConvP& p, hipStream_t stream, const char* what) {
     if (p.B <= 0 || p.ncols <= 0 || p.M <= 0) return RH_OK;
-    if (p.M <= 32) return launch_cfg<1, 2, 1, 4>(p, stream, what);
-    if (p.M <= 64) return launch_cfg<2, 1, 1, 4>(p, stream, what);
-    if (p.M % 96 == 0 || p.M < 96) return launch_cfg<3, 1, 1, 4>(p, stream, what);
-    return launch_cfg<2, 2, 2, 2>(p, stream, what);
+    int rc;
+    if (p.M <= 32) rc = launch_cfg<1, 2, 1, 4>(p, stream, what);
+    else if (p.M <= 64) rc = launch_cfg<2, 1, 1, 4>(p, stream, what);
+    else if (p.M % 96 == 0 || p.M < 96) rc = launch_cfg<3, 1, 1, 4>(p, stream, what);
+    else rc = launch_cfg<2, 2, 2, 2>(p, stream, what);
+    return rc ? rc : rh_range_after(p, stream);
+}
+
+// A launch of a kernel family that does not publish the output's range slot (everything but conv_x6_kernel and its finalize
+// pass): fill a requested slot with one pass over the output.
+int rh_range_after(const ConvP& p, hipStream_t stream) {
+    if (!p.out_range) return RH_OK;
+    return rh_amax_f32(p.out, (int64_t)p.B * (p.Mr > 0 && p.vs > 1 ? p.Mr : p.M) * p.out_row, p.out_range, (rh_stream_t)stream);
 }

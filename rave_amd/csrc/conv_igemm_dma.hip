@@ -321,71 +321,88 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_dma_kernel(const ConvP
 
 unsigned magic_of(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 
-// out = epi( sum_z part[z] ) for split-K launches (ordered sum -> deterministic)
+// out = epi( sum_z part[z] ) for split-K launches (ordered sum -> deterministic).  With p.out_range set (the range slot of the
+// f16 kernels' consumers, common.hpp) the launch also leaves max |out| there: ONE atomic per workgroup, so the grid is capped
+// and strided (every element is still summed by one thread in slice order).
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const ConvP p, long total) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const long row = e / p.out_valid;
-    const int oi = (int)(e - row * p.out_valid);
-    const int m = (int)(row % p.M);
-    const long idx = row * p.out_row + oi;
-    float v = 0.f;
-    for (int z = 0; z < p.ksplit; ++z) v += p.part[(long)z * p.part_stride + idx];
-    if (p.bias) v += p.bias[m];
-    if (p.mul_src) {
-        const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
-        v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
+    float mx = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / p.out_valid;
+        const int oi = (int)(e - row * p.out_valid);
+        const int m = (int)(row % p.M);
+        const long idx = row * p.out_row + oi;
+        float v = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) v += p.part[(long)z * p.part_stride + idx];
+        if (p.bias) v += p.bias[m];
+        if (p.mul_src) {
+            const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
+            v *= rh_act_grad(p.mul_src[idx], p.epi_act, p.epi_slope, al);
+        }
+        if (p.add) v += p.add[idx];
+        if (p.out_act == RH_ACT_LEAKY) v = v > 0.f ? v : v * p.out_slope;
+        p.out[idx] = v;
+        mx = fmaxf(mx, fabsf(v));
     }
-    if (p.add) v += p.add[idx];
-    if (p.out_act == RH_ACT_LEAKY) v = v > 0.f ? v : v * p.out_slope;
-    p.out[idx] = v;
+    if (p.out_range) {
+        __shared__ float red[4];
+        rh_range_publish(p.out_range, mx, blockIdx.x, red);
+    }
 }
 
 // the same, four consecutive outputs of one row per thread (16-byte loads / stores): the launch is a pure stream over
 // ksplit + 1 ... ksplit + 3 tensors, and one element per thread kept too few bytes in flight per lane (2-3.5 TB/s)
 __global__ __launch_bounds__(256) void splitk_finalize4_kernel(const ConvP p, long total4) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total4) return;
-    const long e = 4 * t;
-    const long row = e / p.out_valid;
-    const int oi = (int)(e - row * p.out_valid);
-    const int m = (int)(row % p.M);
-    const long idx = row * p.out_row + oi;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.ksplit; ++z) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(p.part + (long)z * p.part_stride + idx);
+    float mx = 0.f;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total4; t += (long)gridDim.x * 256) {
+        const long e = 4 * t;
+        const long row = e / p.out_valid;
+        const int oi = (int)(e - row * p.out_valid);
+        const int m = (int)(row % p.M);
+        const long idx = row * p.out_row + oi;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.ksplit; ++z) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p.part + (long)z * p.part_stride + idx);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += q[i];
-    }
-    if (p.bias) {
-        const float b = p.bias[m];
+            for (int i = 0; i < 4; ++i) v[i] += q[i];
+        }
+        if (p.bias) {
+            const float b = p.bias[m];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += b;
-    }
-    if (p.mul_src) {
-        const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(p.mul_src + idx);
+            for (int i = 0; i < 4; ++i) v[i] += b;
+        }
+        if (p.mul_src) {
+            const float al = (p.epi_act == RH_ACT_SNAKE) ? p.mul_alpha[m] : 0.f;
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p.mul_src + idx);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= rh_act_grad(q[i], p.epi_act, p.epi_slope, al);
-    }
-    if (p.add) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(p.add + idx);
+            for (int i = 0; i < 4; ++i) v[i] *= rh_act_grad(q[i], p.epi_act, p.epi_slope, al);
+        }
+        if (p.add) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p.add + idx);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += q[i];
-    }
-    if (p.out_act == RH_ACT_LEAKY) {
+            for (int i = 0; i < 4; ++i) v[i] += q[i];
+        }
+        if (p.out_act == RH_ACT_LEAKY) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.out_slope;
+            for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.out_slope;
+        }
+        *reinterpret_cast<f32x4*>(p.out + idx) = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
-    *reinterpret_cast<f32x4*>(p.out + idx) = v;
+    if (p.out_range) {
+        __shared__ float red[4];
+        rh_range_publish(p.out_range, mx, blockIdx.x, red);
+    }
 }
 
 int finalize_launch(const ConvP& p, hipStream_t stream) {
     const long total = (long)p.B * p.M * p.out_valid;
     const bool vec = (p.out_valid & 3) == 0 && (p.out_row & 3) == 0 && (p.part_stride & 3) == 0 &&
                      (((uintptr_t)p.part | (uintptr_t)p.out | (uintptr_t)p.mul_src | (uintptr_t)p.add) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(splitk_finalize4_kernel, dim3((unsigned)rh_cdiv64(total / 4, 256)), dim3(256), 0, stream, p, total / 4);
-    else hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)rh_cdiv64(total, 256)), dim3(256), 0, stream, p, total);
+    const long items = vec ? total / 4 : total;
+    long blocks = rh_cdiv64(items, 256);
+    if (p.out_range && blocks > 1024) blocks = 1024;       // one range atomic per workgroup (see the kernels)
+    if (vec) hipLaunchKernelGGL(splitk_finalize4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, items);
+    else hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, items);
     return rh_check_launch("conv_splitk_finalize");
 }
 
@@ -534,17 +551,23 @@ int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream) { return finalize_la
 
 int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes) {
     fill_sizes(p);
-    {   // stride-1 convolutions of the residual units: exact f32 on the bf16 matrix cores (conv_x6.hip)
+    {   // stride-1 convolutions of the residual units: exact f32 on the 16-bit matrix cores (conv_x6.hip)
         bool used = false;
         if (int e = rh_conv_launch_x6(p, stream, what, ws, ws_bytes, &used)) return e;
         if (used) return RH_OK;
         if (int e = rh_conv_launch_c2x(p, stream, what, &used)) return e;      // stride-3 gathers: 2-D kernel, W = 1
-        if (used) return RH_OK;
+        if (used) return rh_range_after(p, stream);
     }
-    if (p.M <= 32) return launch_dma<1, 2, 1, 4>(p, stream, what, ws, ws_bytes);
-    if (p.M <= 64) return launch_dma<2, 1, 1, 4>(p, stream, what, ws, ws_bytes);
-    if (p.M % 96 == 0 || p.M < 96) return launch_dma<3, 1, 1, 4>(p, stream, what, ws, ws_bytes);
-    return launch_dma<2, 2, 2, 2>(p, stream, what, ws, ws_bytes);
+    // f32-input MFMA kernels: they do not publish the output's range; a requested slot is filled by a pass over the output
+    unsigned* const orange = p.out_range;
+    p.out_range = nullptr;
+    int rc;
+    if (p.M <= 32) rc = launch_dma<1, 2, 1, 4>(p, stream, what, ws, ws_bytes);
+    else if (p.M <= 64) rc = launch_dma<2, 1, 1, 4>(p, stream, what, ws, ws_bytes);
+    else if (p.M % 96 == 0 || p.M < 96) rc = launch_dma<3, 1, 1, 4>(p, stream, what, ws, ws_bytes);
+    else rc = launch_dma<2, 2, 2, 2>(p, stream, what, ws, ws_bytes);
+    p.out_range = orange;
+    return rc ? rc : rh_range_after(p, stream);
 }
 
 int64_t rh_conv_splitk_workspace(ConvP p) {

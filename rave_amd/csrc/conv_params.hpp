@@ -38,9 +38,15 @@ struct ConvP {
     float* part;                               // [ksplit][B][M][out_row] scratch (caller workspace)
     long part_stride;                          // B*M*out_row
     unsigned in_bytes, w_bytes;                // buffer sizes for the bounds-checked DMA descriptors
-    // --- bf16x6 path (conv_x6.hip) only ---
-    const unsigned* wq;                        // pre-split weights: 16-byte fragments [phase][step][g][piece][Mp] (8 bf16 each)
+    // --- x6 path (conv_x6.hip) only ---
+    const unsigned* wq;                        // pre-split weights: 16-byte fragments [phase][step][g][piece][Mp] (8 halves each)
     unsigned wq_bytes;
+    // range slots (common.hpp: RH_X6_F16): max |x| of the input tensor (kRangeWords words; required by the f16 kernels),
+    // where the launch leaves max |out| (kRangeWords words, zeroed by the caller; may be null), and the weights' own record
+    // behind their fragments: {max |w|, max over dim-0 rows of sum |w|, 0, 0} as float bit patterns
+    const unsigned* in_range;
+    unsigned* out_range;
+    const unsigned* w_range;
     int x6_mode;                               // 0 = the packed operand has no bf16x6 section; else the input stride IS the
                                                // section was packed for (1 = plain taps, 2 / 4 = phase-interleaved octets)
     int x6_P;                                  // positions (16-byte fragments) per (octet, piece) plane of the B tile in LDS
@@ -99,8 +105,10 @@ struct PackP {
     const float* w;
     const float* scale;   // per dim-0 slice (weight-norm g/||v||) or null
     float* wp;
-    unsigned* wq;         // bf16x6 section behind the f32 section (conv_x6.hip) or null: 16-byte fragments of 8 bf16,
-                          //   [phase][step][g = octet of the 16-deep MFMA k block][piece 0..2][Mp]
+    unsigned* wq;         // x6 section behind the f32 section (conv_x6.hip) or null: 16-byte fragments of 8 halves,
+                          //   [phase][step][g = octet of the 16-deep MFMA k block][piece 0..kX6P-1][Mp]
+    unsigned* range;      // one 16-byte record behind the fragments: {max |w|, max row sum |w|, 0, 0} (float bits); written by
+                          //   the range kernels BEFORE the pack kernel, which scales the f16 pieces by it
     long total;           // nslots * C * Mp   (0 = nothing to do)
     int C, M, Mp, k;      // k = taps per (m, c) pair in the source tensor
     int nslots;
@@ -108,6 +116,8 @@ struct PackP {
     int x6_mode;          // 0 none; 1: step = (16-channel chunk, tap); IS > 1: step = (16/IS-channel chunk, tap group u),
                           //   k slot kappa of the block <-> channel kappa / IS, source tap u*IS + kappa % IS
     int x6_nu;            // IS > 1: tap groups per chunk = ceil(k / IS)
+    int bf16x3;           // 1: the mode-1 section holds THREE bf16 truncation pieces per value whatever the build (the 2-D
+                          //   kernels' operand: conv2d.hip, conv2d_x6.hip), no range record
     // x6_vs = s > 1: a second section ("virtual rows") at fragment x6_vofs: step = (16-channel chunk, tap u < x6_U),
     // row r = m * s + q2j[slot], rows padded to x6_Mvp, fragment of slot = x6_vofs + vq2a[slot] + chunk * x6_U*6*x6_Mvp;
     // (j, u) pairs no slot covers are written as zeros
@@ -141,6 +151,7 @@ int rh_conv_fill_fwd(const rh_conv1d_desc* d, ConvP* p);
 int rh_conv_fill_dgrad(const rh_conv1d_desc* d, ConvP* p);
 int rh_conv_launch(ConvP& p, hipStream_t stream, const char* what, void* ws = nullptr, int64_t ws_bytes = 0);
 int rh_conv_launch_sync(ConvP& p, hipStream_t stream, const char* what);   // register-staged (all activations)
+int rh_range_after(const ConvP& p, hipStream_t stream);                    // fills p.out_range from the output (kernels that do not publish)
 int rh_conv_launch_dma(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes);
 bool rh_conv_dma_eligible(const ConvP& p);
 int64_t rh_conv_splitk_workspace(ConvP p);     // bytes of scratch the launch would like (0 = none)
@@ -158,6 +169,16 @@ inline int rh_x6_mode(int C, int nphase, int is, int inner, int ntaps0, const in
     for (int t = 0; t < ntaps0; ++t)
         if (off[t] != off[0] + t || kk[t] != t) return 0;
     return is;
+}
+// conv_x6_kernel instances (conv_x6_kernel.inc: x6_launch): epi = operand mode (bit 0 bias, 1 derivative, 2 add, 3 output
+// activation) + 16 * (virtual rows: 1 = runs of 2, 2 = runs of 4); is = input stride of the fragment layout, tm = row tiles per wave
+inline bool rh_x6_epi_instantiated(int is, int tm, bool leaky, int epi) {
+    const int m = epi & 15, v = epi >> 4;
+    if (v) {
+        if (is != 1 || tm < 2 || v > 2) return false;
+        return leaky ? (m == 0 || m == 1 || m == 5) : (m == 0 || m == 1 || m == 2 || m == 4 || m == 5 || m == 6);
+    }
+    return leaky ? (m == 0 || m == 1 || m == 4 || m == 5) : (m == 0 || m == 1 || m == 2 || m == 4 || m == 5 || m == 6 || m == 9 || m == 13);
 }
 int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, int64_t ws_bytes, bool* used);
 // stride-3 gathers with plain-tap fragments on the 2-D bf16x6 kernel (conv2d_x6.hip); query = would this launch take it?

@@ -692,7 +692,8 @@ int launch_w(WgradP& p, const WPlan& w, hipStream_t stream) {
 }  // namespace
 
 int64_t rh_wgrad_x6_workspace(const WgradP& w);
-int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used, int* left_z);
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used, int* left_z,
+                       const unsigned* r_range, const unsigned* s_range);
 int rh_reduce_wn_bwd_launch(const float* part, int Z, long M, long N, const float* v, const float* g, const float* norms,
                             float* dv, float* dg, hipStream_t stream, bool* used);
 
@@ -711,13 +712,15 @@ int64_t rh_wgrad_workspace(const rh_conv1d_desc* d) {
     fill(d, &p);
     const int64_t bias = rh_bias_grad_workspace(d->c_out);
     if (rh_smallc_wgrad_eligible(d)) return bias + rh_smallc_wgrad_workspace(d);
-    if (d->act != RH_ACT_SNAKE) {      // exact f32 on the bf16 matrix cores (conv_wgrad_x6.hip) when the geometry fits
-        const int64_t x6 = rh_wgrad_x6_workspace(p);
-        if (x6 >= 0) return bias + x6;
+    int64_t x6 = -1;
+    if (d->act != RH_ACT_SNAKE) {      // exact f32 on the 16-bit matrix cores (conv_wgrad_x6.hip) when the geometry fits
+        x6 = rh_wgrad_x6_workspace(p);
+        if (x6 >= 0 && !RH_X6_F16) return bias + x6;
     }
+    // (f16 build: a call without range slots falls back to the f32-input kernels -- the scratch covers both plans)
     const WPlan w = plan(p);
-    if (w.Z <= 1) return bias;
-    return bias + (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float);
+    const int64_t f32 = w.Z <= 1 ? 0 : (int64_t)w.Z * p.M * p.C * p.T * (int64_t)sizeof(float);
+    return bias + (x6 > f32 ? x6 : f32);
 }
 
 extern "C" int rh_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norms, int64_t rows,
@@ -729,6 +732,9 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
                  float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t stream, const RhWnTail* tail) {
     WgradP p{};
     fill(d, &p);
+    const unsigned *dy_range = nullptr, *x_range = nullptr;
+    rh_take_ranges(&dy_range, &x_range, nullptr, nullptr);
+    const bool have_ranges = !RH_X6_F16 || (dy_range && x_range);
     auto through_dw = [&](int e) {
         if (e || !tail) return e;
         return rh_weight_norm_bwd_f32(dw, tail->v, tail->g, tail->norms, p.M, (int64_t)p.C * p.T, tail->dv, tail->dg, (rh_stream_t)stream);
@@ -744,7 +750,7 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
         return through_dw(rh_smallc_wgrad(d, dy, x, dw, dbias, ws, stream));
     }
     // Conv1d on the bf16x6 weight-gradient kernel: the bias gradient (row sums of dy) comes out of the same pass
-    const bool x6_path = d->act != RH_ACT_SNAKE && p.B > 0 && p.r_row > 0 && rh_wgrad_x6_workspace(p) >= 0;
+    const bool x6_path = have_ranges && d->act != RH_ACT_SNAKE && p.B > 0 && p.r_row > 0 && rh_wgrad_x6_workspace(p) >= 0;
     const bool fuse_bias = x6_path && !d->transposed && dbias != nullptr;
     if (dbias && d->batch > 0 && !fuse_bias) {
         RH_REQUIRE(ws && ws_bytes >= bias_ws, RH_ERR_WORKSPACE, "conv1d_bwd_weight: workspace %lld B < %lld B",
@@ -761,14 +767,16 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
         if (dbias) (void)hipMemsetAsync(dbias, 0, d->c_out * sizeof(float), stream);
         return through_dw(RH_OK);
     }
-    if (d->act != RH_ACT_SNAKE) {
+    if (d->act != RH_ACT_SNAKE && have_ranges) {
         const int64_t x6 = rh_wgrad_x6_workspace(p);
         if (x6 >= 0) {
             RH_REQUIRE(x6 == 0 || (ws && ws_bytes >= x6), RH_ERR_WORKSPACE,
                        "conv1d_bwd_weight: workspace %lld B < %lld B", (long long)ws_bytes, (long long)x6);
             bool used = false;
             int left_z = 0;      // > 0: the partials were left unreduced in ws for the fused tail
-            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used, tail ? &left_z : nullptr)) return e;
+            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used, tail ? &left_z : nullptr,
+                                           d->transposed ? x_range : dy_range, d->transposed ? dy_range : x_range))
+                return e;
             if (used && left_z > 1) {
                 bool fused = false;
                 if (int e = rh_reduce_wn_bwd_launch((const float*)ws, left_z, p.M, (long)p.C * p.T, tail->v, tail->g, tail->norms,

@@ -31,7 +31,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOOB = 0x80000000u;
 
@@ -48,6 +47,8 @@ struct Wx6P {
     unsigned r_bytes, s_bytes;
     int minoff, maxoff;
     int p8, cpb, chmax;         // plane mode (PL): octets of a channel image, channel pitch in bytes, channel images reserved
+    const unsigned* r_range;    // range slots of R and S (f16 build: common.hpp)
+    const unsigned* s_range;
     int off[kMaxTaps];
 };
 
@@ -57,19 +58,29 @@ __device__ __forceinline__ u32x4 wx6_lds_read_b128_any(unsigned addr) {      // 
     return v;
 }
 
-// LeakyReLU (slope in [0, 1]; 1 = none) + exact 3-way bf16 split of 8 samples -> three 16-byte fragments, ~7.5 VALU
-// instructions per sample: max(x, slope x), two mask / subtract rounds, one byte permute per packed pair.  VALU work
-// is NOT free next to the matrix cores on this chip (tools/probe/mfma_valu_overlap.hip: an MFMA + 6 VALU take 46 cycles
-// against 40 for the MFMA alone, in one wave or across two) -- every instruction saved here is matrix time.
-__device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* dst, int piece_stride) {
+// LeakyReLU (slope in [0, 1]; 1 = none) + split of 8 samples -> kX6P 16-byte fragments.  f16 build: the samples are scaled
+// by `sc` (power of two, from the operand's range slot) and split hi / lo with packed converts, ~5 VALU per sample; bf16 build:
+// exact 3-way truncation split, ~7.5.  VALU work is NOT free next to the matrix cores on this chip
+// (tools/probe/mfma_valu_overlap.hip) -- every instruction saved here is matrix time.
+__device__ __forceinline__ void emit(const float (&v)[8], float slope, float sc, u32x4* dst, int piece_stride) {
+#if RH_X6_F16
+    u32x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a = v[2 * k] * sc, b = v[2 * k + 1] * sc;
+        a = rh_max1(a, a * slope);
+        b = rh_max1(b, b * slope);
+        const rh_h2 h = rh_h2_split(a, b);
+        hi[k] = h.hi; lo[k] = h.lo;
+    }
+    dst[0] = hi;
+    dst[piece_stride] = lo;
+#else
     unsigned h[3][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float x = rh_max1(v[i], v[i] * slope);
-        h[0][i] = __float_as_uint(x);
-        const float r1 = x - __uint_as_float(h[0][i] & 0xffff0000u);
-        h[1][i] = __float_as_uint(r1);
-        h[2][i] = __float_as_uint(r1 - __uint_as_float(h[1][i] & 0xffff0000u));
+        rh_bf3_split(x, h[0][i], h[1][i], h[2][i]);
     }
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
@@ -78,6 +89,7 @@ __device__ __forceinline__ void emit(const float (&v)[8], float slope, u32x4* ds
         for (int k = 0; k < 4; ++k) pk[k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);   // high halves
         dst[s3 * piece_stride] = pk;
     }
+#endif
 }
 
 constexpr int kKS = 2;     // MFMA k blocks (16 positions each) per step
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     // the four octets of one row write to (k block, g) = (0,0), (0,1), (1,0), (1,1): without the padding those blocks are
     // 3 * BM fragments = a multiple of 256 bytes apart and every ds_write_b128 was a 4-way bank conflict (PMC:
     // SQ_LDS_BANK_CONFLICT 60 % of SQ_LDS_IDX_ACTIVE); with it the four lanes land 64 bytes apart.
-    constexpr int A_GS = 3 * BM + 4, B_GS = 3 * BN + 4;                   // g stride
+    constexpr int A_GS = kX6P * BM + 4, B_GS = kX6P * BN + 4;             // g stride
     constexpr int A_UNITS = 2 * A_GS, B_UNITS = 2 * B_GS;                 // k-block stride
     constexpr int OCT = 2 * kKS;                                          // 8-sample octets per row and step
     constexpr int NA = (OCT * BM + 255) / 256;                                // tasks per thread and step
@@ -127,6 +139,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
     const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.S), 0, p.s_bytes, 0x00020000);
+#if RH_X6_F16
+    int inv_r, inv_s;
+    const float rsc = __uint_as_float(rh_x6_scale_bits(rh_range_max(p.r_range), &inv_r));
+    const float ssc = __uint_as_float(rh_x6_scale_bits(rh_range_max(p.s_range), &inv_s));
+    const float osc = __uint_as_float(rh_x6_unscale_bits(inv_r, inv_s));
+#else
+    const float rsc = 1.f, ssc = 1.f, osc = 1.f;
+#endif
 
     // ---- tasks (step-invariant).  A task = 8 consecutive samples of one row; consecutive lanes take consecutive
     // octets of the SAME row (OCT lanes x 32 bytes = one 128-byte line per row), so that a load instruction touches
@@ -247,12 +267,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
         }
 #pragma unroll
         for (int q = 0; q < NA; ++q)
-            if (adst[q] >= 0) emit(ra[q], p.r_slope, a_st + adst[q], BM);
+            if (adst[q] >= 0) emit(ra[q], p.r_slope, rsc, a_st + adst[q], BM);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             if (bdst[q] < 0) continue;
-            if constexpr (PL) emit(rb[q], p.s_slope, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(b_st) + bdst[q]), (int)(b_piece >> 4));
-            else emit(rb[q], p.s_slope, b_st + bdst[q], BN);
+            if constexpr (PL) emit(rb[q], p.s_slope, ssc, reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(b_st) + bdst[q]), (int)(b_piece >> 4));
+            else emit(rb[q], p.s_slope, ssc, b_st + bdst[q], BN);
         }
     };
 
@@ -280,12 +300,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
             for (int kb = 0; kb < kKS; ++kb) {
                 const u32x4* al = a_st + kb * A_UNITS + arow;
                 const u32x4* bl = b_st + kb * B_UNITS + bcol;
-                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
-                bf16x8 afr[TM][3];
+                constexpr int SA[RH_X6_NPROD] = RH_X6_SA, SB[RH_X6_NPROD] = RH_X6_SB;     // smallest terms first
+                rh_x6_frag afr[TM][kX6P];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+                    for (int s3 = 0; s3 < kX6P; ++s3) afr[tm][s3] = __builtin_bit_cast(rh_x6_frag, al[s3 * BM + tm * 32]);
                 if constexpr (PL) {
                     // the 8 positions 16 kb + 8 g .. + 7 of the column's channel image, shifted by its tap: an unaligned read.
                     // One column tile at a time (three fragments in registers, not six): every accumulator still receives its
@@ -294,30 +314,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
                         if (tn == 1 && !live2) break;                                   // wave-uniform
-                        u32x4 b0 = wx6_lds_read_b128_any(bo + bcolb[tn]), b1 = wx6_lds_read_b128_any(bo + bcolb[tn] + b_piece),
-                              b2 = wx6_lds_read_b128_any(bo + bcolb[tn] + 2u * b_piece);
+                        u32x4 b0 = wx6_lds_read_b128_any(bo + bcolb[tn]), b1 = wx6_lds_read_b128_any(bo + bcolb[tn] + b_piece);
+                        u32x4 b2 = kX6P == 3 ? wx6_lds_read_b128_any(bo + bcolb[tn] + 2u * b_piece) : b1;
                         // (the compiler does not count the asm reads: wait for everything LDS has in flight)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2));
-                        const bf16x8 bf[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
+                        const rh_x6_frag bf[3] = {__builtin_bit_cast(rh_x6_frag, b0), __builtin_bit_cast(rh_x6_frag, b1), __builtin_bit_cast(rh_x6_frag, b2)};
 #pragma unroll
-                        for (int q = 0; q < 6; ++q)
+                        for (int q = 0; q < RH_X6_NPROD; ++q)
 #pragma unroll
                             for (int tm = 0; tm < TM; ++tm)
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bf[SB[q]], acc[tm][tn], 0, 0, 0);
+                                acc[tm][tn] = RH_X6_MFMA(afr[tm][SA[q]], bf[SB[q]], acc[tm][tn]);
                     }
                 } else {
-                    bf16x8 bfr[2][3];
+                    rh_x6_frag bfr[2][kX6P];
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn)           // (a dead tile's slots hold stale data: read, never multiplied)
 #pragma unroll
-                        for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl[s3 * BN + tn * 32]);
+                        for (int s3 = 0; s3 < kX6P; ++s3) bfr[tn][s3] = __builtin_bit_cast(rh_x6_frag, bl[s3 * BN + tn * 32]);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < RH_X6_NPROD; ++q)
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm) {
-                            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[0][SB[q]], acc[tm][0], 0, 0, 0);
-                            if (live2)
-                                acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[1][SB[q]], acc[tm][1], 0, 0, 0);
+                            acc[tm][0] = RH_X6_MFMA(afr[tm][SA[q]], bfr[0][SB[q]], acc[tm][0]);
+                            if (live2) acc[tm][1] = RH_X6_MFMA(afr[tm][SA[q]], bfr[1][SB[q]], acc[tm][1]);
                         }
                 }
             }
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) outz[(long)m * p.N + col] = acc[tm][tn][r];
+                if (m < p.M) outz[(long)m * p.N + col] = RH_X6_F16 ? acc[tm][tn][r] * osc : acc[tm][tn][r];
             }
         }
     }
@@ -362,9 +381,10 @@ struct Wx6Plan {
     size_t lds;
 };
 
-bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
+bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl, const unsigned* r_range, const unsigned* s_range) {
     const char* e = getenv("RH_WGRAD_X6");        // read per call: the parity tests flip it at run time
     if (e && atoi(e) == 0) return false;
+    if (RH_X6_F16 && (!r_range || !s_range)) return false;      // no range slots (rh_x6_set_ranges): f32-input MFMA kernels
     if (w.inner != 1 || w.T > kMaxTaps || w.B <= 0 || w.r_row <= 0) return false;
     if ((w.r_act != RH_ACT_NONE && w.r_act != RH_ACT_LEAKY) || (w.s_act != RH_ACT_NONE && w.s_act != RH_ACT_LEAKY)) return false;
     // the conversion applies LeakyReLU as max(x, slope x)
@@ -391,6 +411,7 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
     p->total_steps = w.B * p->steps_per_b;
     p->r_bytes = (unsigned)rb; p->s_bytes = (unsigned)sb;
     p->minoff = w.minoff; p->maxoff = w.maxoff;
+    p->r_range = r_range; p->s_range = s_range;
     for (int t = 0; t < w.T; ++t) p->off[t] = w.off[t];
     const int Mp = (w.M + 31) & ~31;
     // 96-row wave tiles (TM = 3: 216 VGPRs, two workgroups per CU) convert the least per MFMA, but 64-row ones (TM = 2:
@@ -412,13 +433,13 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl) {
         const bool on = pe && pe[0] == '1';                      // OPT-IN: measured slower, see the kernel's header comment
         const int reach = w.maxoff - w.minoff;
         const int p8 = (32 + reach + 7) / 8;
-        pl->planes = on && w.is == 1 && w.T >= 2 && reach >= 0 && p8 <= 7 && 4l * (w.s_row + 64) * w.C * w.B < 0x7fffffffl;
+        pl->planes = on && pl->tm >= 2 && w.is == 1 && w.T >= 2 && reach >= 0 && p8 <= 7 && 4l * (w.s_row + 64) * w.C * w.B < 0x7fffffffl;
         p->p8 = p8;
         p->cpb = 16 * ((p8 & 1) ? p8 : p8 + 1);                 // odd number of 16-byte slots: channel images start on different banks
         p->chmax = BN / w.T + 2;
     }
-    const size_t a_bytes = (size_t)kKS * 2 * (3 * BM + 4) * 16;
-    pl->lds = a_bytes + (pl->planes ? (size_t)3 * p->chmax * p->cpb + 32 : (size_t)kKS * 2 * (3 * BN + 4) * 16);
+    const size_t a_bytes = (size_t)kKS * 2 * (kX6P * BM + 4) * 16;
+    pl->lds = a_bytes + (pl->planes ? (size_t)kX6P * p->chmax * p->cpb + 32 : (size_t)kKS * 2 * (kX6P * BN + 4) * 16);
     // K slices: one round of workgroups (512) -- every extra slice is another copy of the whole weight tensor written and
     // re-read.  (Rounds 2-4 ran two rounds, 1024, when the weight tensor has >= 32 tiles: measured per layer then, slower
     // in the step now.)
@@ -450,8 +471,11 @@ void go4(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
 
 template <int TM, int WM, bool AV, bool PART>
 void go3(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
-    if (pl.planes) go4<TM, WM, AV, PART, true>(p, pl, stream);
-    else go4<TM, WM, AV, PART, false>(p, pl, stream);
+    // (no plane-mode instance for 32-row wave tiles: the opt-in mode is slower anyway and that instance needed scratch)
+    if constexpr (TM >= 2) {
+        if (pl.planes) return go4<TM, WM, AV, PART, true>(p, pl, stream);
+    }
+    go4<TM, WM, AV, PART, false>(p, pl, stream);
 }
 
 template <int TM, int WM, bool AV>
@@ -473,7 +497,8 @@ void go(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
 int64_t rh_wgrad_x6_workspace(const WgradP& w) {
     Wx6P p;
     Wx6Plan pl{};
-    if (!plan_wx6(w, &p, &pl)) return -1;
+    static const unsigned any_range[kRangeWords] = {};      // planning only: the answer does not depend on the slots
+    if (!plan_wx6(w, &p, &pl, any_range, any_range)) return -1;
     // partial weight tiles (Z > 1) + partial row sums for the fused bias gradient (always reserved)
     return (pl.Z > 1 ? (int64_t)pl.Z * w.M * w.C * w.T : 0) * (int64_t)sizeof(float) + (int64_t)pl.Z * w.M * (int64_t)sizeof(float);
 }
@@ -482,12 +507,13 @@ int64_t rh_wgrad_x6_workspace(const WgradP& w) {
 // rsum_out != null: also the row sums of R over (batch, position) -- the bias gradient when R = dy -- from the same pass
 // left_z != null and the K range was split: the weight partials stay UNREDUCED in ws ([Z][M][C*T], *left_z = Z) for a caller
 // that folds the reduction into its next pass (conv_wgrad.hip: reduce_wn_bwd_kernel); the bias partials are reduced here.
-int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used, int* left_z) {
+int rh_wgrad_x6_launch(const WgradP& w, float* dw, float* rsum_out, void* ws, hipStream_t stream, bool* used, int* left_z,
+                       const unsigned* r_range, const unsigned* s_range) {
     *used = false;
     if (left_z) *left_z = 0;
     Wx6P p;
     Wx6Plan pl{};
-    if (!plan_wx6(w, &p, &pl)) return RH_OK;
+    if (!plan_wx6(w, &p, &pl, r_range, s_range)) return RH_OK;
     p.out = pl.Z > 1 ? (float*)ws : dw;
     float* const rs_part = (float*)ws + (pl.Z > 1 ? (long)pl.Z * w.M * w.C * w.T : 0);
     p.rsum = rsum_out ? (pl.Z > 1 ? rs_part : rsum_out) : nullptr;

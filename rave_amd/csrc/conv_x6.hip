@@ -3,9 +3,37 @@
 #include "conv_params.hpp"
 #include "conv2d_x6.hpp"
 
-void rh_x6_dispatch_is1(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
-void rh_x6_dispatch_is2(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
-void rh_x6_dispatch_is4(const ConvP& q, int tm, int tn, int wm, dim3 grid, size_t lds, hipStream_t stream);
+// one translation unit per (input stride, tile shape): conv_x6_i<IS>_<TM><TN><WM>.hip
+bool rh_x6_launch_i1_121(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_221(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_321(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_122(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_222(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_322(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_211(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_311(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_212(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i1_312(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_121(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_221(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_321(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_122(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_222(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_322(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_211(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_311(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_212(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i2_312(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_121(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_221(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_321(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_122(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_222(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_322(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_211(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_311(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_212(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
+bool rh_x6_launch_i4_312(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
 int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream);
 
 namespace {
@@ -16,6 +44,19 @@ struct X6Plan {
     int tm, tn, wm, wn, ksplit, chunks_per_split, col_tiles, row_tiles;
 };
 
+typedef bool (*X6Launch)(const ConvP&, int, dim3, size_t, hipStream_t);
+X6Launch x6_launcher(int is, int tm, int tn, int wm) {
+#define RH_X6_S(IS_, TM_, TN_, WM_) if (is == IS_ && tm == TM_ && tn == TN_ && wm == WM_) return rh_x6_launch_i##IS_##_##TM_##TN_##WM_;
+#define RH_X6_SHAPES(IS_) \
+    RH_X6_S(IS_, 1, 2, 1) RH_X6_S(IS_, 2, 2, 1) RH_X6_S(IS_, 3, 2, 1) RH_X6_S(IS_, 1, 2, 2) RH_X6_S(IS_, 2, 2, 2) RH_X6_S(IS_, 3, 2, 2) \
+    RH_X6_S(IS_, 2, 1, 1) RH_X6_S(IS_, 3, 1, 1) RH_X6_S(IS_, 2, 1, 2) RH_X6_S(IS_, 3, 1, 2)
+    RH_X6_SHAPES(1) RH_X6_SHAPES(2) RH_X6_SHAPES(4)
+#undef RH_X6_SHAPES
+#undef RH_X6_S
+    return nullptr;
+}
+int epi_mode(const ConvP& p) { return (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0); }
+
 bool x6_enabled() {
     const char* e = getenv("RH_CONV_X6");      // read per call: the parity tests flip it at run time
     return !(e && atoi(e) == 0);
@@ -23,6 +64,7 @@ bool x6_enabled() {
 
 bool plan_x6(ConvP& p, X6Plan* pl) {
     if (!x6_enabled() || p.x6_mode == 0) return false;
+    if (RH_X6_F16 && !p.in_range) return false;       // no range slot for the input (rh_x6_set_ranges): f32-input MFMA kernels
     p.vs = 0;
     p.Mr = p.M;
     // Virtual rows (conv_host.hip: vplan_of; second section of the packed operand): the s output phases become s * M
@@ -39,8 +81,9 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
             while (w < n) w <<= 1;
             return w / 128.0;
         };
-        const int mode = (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
-        const bool epi_ok = mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 6;
+        const int mvp = (p.Mr * s + 31) & ~31;
+        const int tmv = mvp % 96 == 0 ? 3 : (mvp % 64 == 0 ? 2 : 1);
+        const bool epi_ok = rh_x6_epi_instantiated(1, tmv, p.in_act == RH_ACT_LEAKY, epi_mode(p) | (s == 2 ? 16 : 32));
         if (epi_ok && tiles(p.ncols + extra) <= 1.07 * tiles(p.ncols)) {
             p.vs = s;
             p.M = p.Mr * s;
@@ -55,11 +98,9 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     if (p.x6_mode != p.is) return false;
     if (p.in_act == RH_ACT_SNAKE || p.epi_act == RH_ACT_SNAKE) return false;
     if (p.in_act == RH_ACT_LEAKY && !(p.in_slope >= 0.f && p.in_slope <= 1.f)) return false;      // applied as max(x, slope x)
-    {   // epilogue operand combinations the kernel carries a specialised copy for (bit 0 bias, 1 derivative, 2 add,
-        // 3 output activation); everything the modules use -- anything else takes the f32 kernels
-        const int mode = (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
-        if (!(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 9 || mode == 13)) return false;
-    }
+    // epilogue operand combinations there is a kernel instance for (bit 0 bias, 1 derivative, 2 add, 3 output activation):
+    // everything the modules use -- anything else takes the f32 kernels
+    if (!rh_x6_epi_instantiated(p.is, 3, p.in_act == RH_ACT_LEAKY, epi_mode(p))) return false;
     if (p.is != 1 && (p.inner != 1 || p.nphase != 1)) return false;
     if (((uintptr_t)p.wq & 15) || ((uintptr_t)p.in & 3)) return false;
     const int is = p.is;
@@ -91,8 +132,8 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
         p.x6_P = p.nb * p.pitch;
         const int nq = pl->wn * tn == 8 ? 3 : 2;
         if (2 * p.x6_P > 256 * nq) return 0;
-        p.x6_a_units = 6 * BM;
-        p.x6_b_units = 6 * p.x6_P;
+        p.x6_a_units = 2 * kX6P * BM;
+        p.x6_b_units = 2 * kX6P * p.x6_P;
         pl->lds = (size_t)(2 * p.x6_a_units + 2 * p.x6_b_units) * 16;
         if (pl->lds > 160 * 1024) return 0;
         pl->col_tiles = rh_cdiv(p.B, p.nb) * p.tiles_per_b;
@@ -147,6 +188,7 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
 bool rh_conv_x6_plan_fixed(ConvP& p, int tm, int tn, int wm, size_t* lds, dim3* grid) {
     if (!x6_enabled() || p.x6_mode != 1 || p.is != 1 || p.inner != 1 || p.nphase != 1) return false;
     if (((uintptr_t)p.in & 3)) return false;
+    if (RH_X6_F16 && !p.in_range) return false;
     p.vs = 0;
     p.Mr = p.M;
     const int wn = 4 / wm;
@@ -166,8 +208,8 @@ bool rh_conv_x6_plan_fixed(ConvP& p, int tm, int tn, int wm, size_t* lds, dim3* 
     p.x6_P = p.nb * p.pitch;
     const int nq = wn * tn == 8 ? 3 : 2;
     if (2 * p.x6_P > 256 * nq) return false;
-    p.x6_a_units = 6 * BM;
-    p.x6_b_units = 6 * p.x6_P;
+    p.x6_a_units = 2 * kX6P * BM;
+    p.x6_b_units = 2 * kX6P * p.x6_P;
     *lds = (size_t)(2 * p.x6_a_units + 2 * p.x6_b_units) * 16;
     if (*lds > 160 * 1024) return false;
     p.ksplit = 1;
@@ -182,6 +224,8 @@ bool rh_conv_x6_plan_fixed(ConvP& p, int tm, int tn, int wm, size_t* lds, dim3* 
 
 int64_t rh_conv_x6_workspace(ConvP p) {
     X6Plan pl{};
+    static const unsigned any_range[kRangeWords] = {};
+    if (!p.in_range) p.in_range = any_range;           // planning only: the answer does not depend on the slot
     if (!plan_x6(p, &pl)) return -1;
     return pl.part_bytes;
 }
@@ -190,6 +234,8 @@ int64_t rh_conv_x6_workspace(ConvP p) {
 // out = {tm, tn, wm, ksplit, input stride of the fragment layout, vs, workgroups}; false = the geometry does not take this path.
 bool rh_conv_x6_plan_query(ConvP p, int* out) {
     X6Plan pl{};
+    static const unsigned any_range[kRangeWords] = {};
+    if (!p.in_range) p.in_range = any_range;
     if (!plan_x6(p, &pl)) return false;
     out[0] = pl.tm; out[1] = pl.tn; out[2] = pl.wm; out[3] = pl.ksplit;
     out[4] = p.is;
@@ -209,18 +255,22 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
         pl.chunks_per_split = (q.C * q.is) >> 4;
     }
     q.in_bytes = (unsigned)(4ull * q.B * q.C * (unsigned long long)q.in_row);
+    q.w_range = q.wq + q.wq_bytes / 4;                 // the range record behind the fragments (conv_host.hip: fill_pack)
     q.part = (float*)ws;
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;
     dim3 grid(pl.col_tiles, pl.row_tiles, q.nphase * q.ksplit);
-    if (q.is == 1) rh_x6_dispatch_is1(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
-    else if (q.is == 2) rh_x6_dispatch_is2(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
-    else rh_x6_dispatch_is4(q, pl.tm, pl.tn, pl.wm, grid, pl.lds, stream);
+    // the epilogue is a template parameter of the kernel: K-slice launches store raw partial sums (mode 0)
+    const int epi = (q.ksplit > 1 ? 0 : epi_mode(q)) | (q.vs == 2 ? 16 : (q.vs == 4 ? 32 : 0));
+    const X6Launch go = x6_launcher(q.is, pl.tm, pl.tn, pl.wm);
+    RH_REQUIRE(go && go(q, epi, grid, pl.lds, stream), RH_ERR_UNSUPPORTED, "%s: no conv_x6_kernel instance for stride %d tile %d%d%d epilogue %d",
+               what, q.is, pl.tm, pl.tn, pl.wm, epi);
     if (int e = rh_check_launch(what)) return e;
     *used = true;
     if (q.ksplit > 1) {            // the partial sums are laid out like the output: finalize with the caller's (real-row) view
         ConvP f = p;
         f.part = q.part; f.ksplit = q.ksplit; f.part_stride = q.part_stride;
+        f.out_range = q.out_range;                     // the finalize pass sees the final values: it publishes their max
         return rh_splitk_finalize_launch(f, stream);
     }
     return RH_OK;
@@ -232,6 +282,7 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
 // on the f32 kernels.
 namespace {
 bool fill_c2x_from_1d(const ConvP& p, C2X* q) {
+    if (RH_X6_F16) return false;      // the 1-D operand holds f16 pieces in this build; the 2-D kernel multiplies bf16 ones
     if (p.x6_mode != 1 || p.is == 1 || p.is == 2 || p.is == 4 || p.inner != 1 || p.nphase != 1 || p.os != 1) return false;
     if (p.in_act != RH_ACT_NONE || p.epi_act != RH_ACT_NONE || p.mul_src || p.add || p.in_alpha || p.mul_alpha) return false;
     if (p.in_row != p.in_valid || p.out_row != p.out_valid || p.ph_ntaps[0] < 1 || p.ph_ntaps[0] > kMaxTaps) return false;

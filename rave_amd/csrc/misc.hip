@@ -834,3 +834,29 @@ extern "C" int rh_adain_transfer_f32(const float* x, int64_t rows, int32_t l, co
                        mean_x, std_x, mean_y, std_y, y);
     return rh_check_launch("adain_transfer");
 }
+
+// ---- range slot of a tensor no kernel of this library produced (common.hpp: RH_X6_F16; include/rave_hip.h: rh_amax_f32) ----
+namespace {
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long n, unsigned* slot) {
+    float m = 0.f;
+    const long n4 = ((uintptr_t)x & 15) == 0 ? n >> 2 : 0;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    __shared__ float red[4];
+    rh_range_publish(slot, m, blockIdx.x, red);
+}
+}  // namespace
+
+extern "C" int rh_amax_f32(const float* x, int64_t n, uint32_t* slot, rh_stream_t stream) {
+    RH_REQUIRE(slot && (x || n == 0) && n >= 0, RH_ERR_INVALID, "amax: bad arguments");
+    if (n == 0) return RH_OK;
+    long blocks = (n / 4 + 1023) / 1024;          // >= 4 16-byte loads per thread
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, slot);
+    return rh_check_launch("amax");
+}

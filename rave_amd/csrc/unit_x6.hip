@@ -32,6 +32,8 @@ struct UnitP {
     unsigned wq1_bytes;
     float slope2;              // LeakyReLU slope applied to h (1 = none)
     float* h_out;              // h for the backward pass, or null (no-grad forward)
+    const unsigned* w1_range;  // range record of the 1x1 conv's weights (behind its fragments)
+    unsigned* h_range;         // where max |h| goes (range slot of the backward pass's consumers), or null
 };
 
 template <int TM, int TN>
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
     const ConvP& p = u.c;
     constexpr int WN = 4;
     constexpr int BM = 32 * TM;
-    constexpr int A_UNITS = 6 * BM;
+    constexpr int A_UNITS = 2 * kX6P * BM;
     constexpr int NAL = (A_UNITS + 255) / 256;
     constexpr int NQ = WN * TN == 8 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -62,6 +64,24 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
 
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.wq), 0, p.wq_bytes, 0x00020000);
+#if RH_X6_F16
+    // scales (common.hpp).  x: its range slot; W3, W1: their records.  h is converted in registers before its maximum can be
+    // known: it is scaled by the BOUND max |x| * max_m sum_k |W3[m][k]| (the record's second word) -- a few bits above the
+    // true maximum, paid out of the 15 bits of headroom the two-piece representation has below the tensor maximum.
+    int inv_x, inv_w3, inv_h, inv_w1;
+    const unsigned xmax = rh_range_max(p.in_range);
+    const float xsc = __uint_as_float(rh_x6_scale_bits(xmax, &inv_x));
+    (void)rh_x6_scale_bits(p.w_range[0], &inv_w3);
+    const float osc1 = __uint_as_float(rh_x6_unscale_bits(inv_w3, inv_x));                   // accumulators of GEMM 1 -> h
+    const float hbound = __uint_as_float(xmax) * __uint_as_float(p.w_range[1]);
+    const unsigned hsc_bits = rh_x6_scale_bits(__float_as_uint(hbound), &inv_h);
+    (void)rh_x6_scale_bits(u.w1_range[0], &inv_w1);
+    const float osc2 = __uint_as_float(rh_x6_unscale_bits(inv_w1, inv_h));                   // accumulators of GEMM 2 -> conv1(h)
+    // accumulators of GEMM 1 -> scaled h in ONE multiplication: osc1 * hsc, exponents added and clamped
+    const float h2sc = __uint_as_float(rh_x6_unscale_bits((int)(__float_as_uint(osc1) >> 23), (int)(hsc_bits >> 23)));
+#else
+    const float xsc = 1.f, osc1 = 1.f, osc2 = 1.f, h2sc = 1.f;
+#endif
 
     int bpos[TN];
 #pragma unroll
@@ -70,9 +90,9 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
         const int bl = col >> p.bnl_shift;
         const int nl = col & (p.bnl - 1);
         const int n = min(n0 + nl, p.ncols - 1);
-        bpos[tn] = g * 3 * P + bl * pitch + (n - n0);
+        bpos[tn] = g * kX6P * P + bl * pitch + (n - n0);
     }
-    const int arow = g * 3 * BM + j;
+    const int arow = g * kX6P * BM + j;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -90,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
         const int gs = uu / BM, mrow = uu - gs * BM;
         aoff[r] = (uu < A_UNITS && mrow < p.Mp) ? (unsigned)((gs * p.Mp + mrow) * 16) : kOOB;
     }
-    const unsigned step_bytes = (unsigned)(6 * p.Mp * 16);
+    const unsigned step_bytes = (unsigned)(2 * kX6P * p.Mp * 16);
     unsigned xoff[NQ];
     int xdst[NQ];
 #pragma unroll
@@ -101,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
         const int bl = pp / pitch, qq = pp - bl * pitch;
         const bool task = e < 2 * P;
         const bool bok = task && b0 + bl < p.B;
-        xdst[q] = task ? o * 3 * P + pp : -1;
+        xdst[q] = task ? o * kX6P * P + pp : -1;
         const int f = n0 + minoff + qq;
         const bool ok = bok && f >= 0 && f < p.in_valid;
         xoff[q] = ok ? (unsigned)((((b0 + bl) * p.C + 8 * o) * p.in_row + f) * 4) : kOOB;
@@ -121,27 +141,39 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
             for (int i = 0; i < 8; ++i)
                 xr[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, xoff[q], cbv + rowc[i], 0));
     };
-    auto split8 = [&](const float (&v)[8], float slope, u32x4 (&pk)[3]) {
+    // activation (max(v, slope v)) + split of 8 values that are multiplied by `sc` first (a power of two; 1 in the bf16 build)
+    auto split8 = [&](const float (&v)[8], float slope, float sc, u32x4 (&pk)[kX6P]) {
+#if RH_X6_F16
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = v[2 * k] * sc, b = v[2 * k + 1] * sc;
+            a = rh_max1(a, a * slope);
+            b = rh_max1(b, b * slope);
+            const rh_h2 h = rh_h2_split(a, b);
+            pk[0][k] = h.hi; pk[1][k] = h.lo;
+        }
+#else
         unsigned h[3][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float a = rh_max1(v[i], v[i] * slope);
-            rh_x6_split(a, h[0][i], h[1][i], h[2][i]);
+            rh_bf3_split(a, h[0][i], h[1][i], h[2][i]);
         }
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
             for (int k = 0; k < 4; ++k) pk[s3][k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);
+#endif
     };
     auto convert_x = [&](int stage) {
-        u32x4* dst0 = b_st + stage * 6 * P;
+        u32x4* dst0 = b_st + stage * 2 * kX6P * P;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (xdst[q] < 0) continue;
-            u32x4 pk[3];
-            split8(xr[q], slope1, pk);
+            u32x4 pk[kX6P];
+            split8(xr[q], slope1, xsc, pk);
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) dst0[xdst[q] + s3 * P] = pk[s3];
+            for (int s3 = 0; s3 < kX6P; ++s3) dst0[xdst[q] + s3 * P] = pk[s3];
         }
     };
     const int nchunks = p.C >> 4;
@@ -173,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
     int st = 0;
     int toff_next = p.off[tap0] - minoff;
     for (int ci = 0; ci < nchunks; ++ci) {
-        const u32x4* bl_ = b_st + (ci & 1) * 6 * P;
+        const u32x4* bl_ = b_st + (ci & 1) * 2 * kX6P * P;
         for (int t = 0; t < nu; ++t, ++st) {
             const int toff = toff_next;
             {
@@ -181,15 +213,15 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
                 toff_next = p.off[tap0 + t1] - minoff;
             }
             const u32x4* al = a_st + (st & 1) * A_UNITS + arow;
-            bf16x8 bfr[TN][3], afr[TM][3];
+            rh_x6_frag bfr[TN][kX6P], afr[TM][kX6P];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, bl_[bpos[tn] + s3 * P + toff]);
+                for (int s3 = 0; s3 < kX6P; ++s3) bfr[tn][s3] = __builtin_bit_cast(rh_x6_frag, bl_[bpos[tn] + s3 * P + toff]);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+                for (int s3 = 0; s3 < kX6P; ++s3) afr[tm][s3] = __builtin_bit_cast(rh_x6_frag, al[s3 * BM + tm * 32]);
             if (st + 1 < S) {
                 store_a((st + 1) & 1);
                 if (st + 2 < S) load_a(st + 2);
@@ -204,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = RH_X6_MFMA(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn]);
             __syncthreads();
         }
     }
@@ -225,13 +257,15 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
     const auto x_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.add), 0, obytes, 0x00020000);
     const auto none_r = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(nullptr), 0, 0, 0x00020000);
     const bool full = BM <= p.M;
+    float hmax_all = 0.f;
     if (u.h_out) {      // training: h for the backward pass; the stores drain under GEMM 2
         const auto h_r = __builtin_amdgcn_make_buffer_rsrc(u.h_out, 0, obytes, 0x00020000);
-        x6_store_tile<0, TM, TN>(acc, cb, 0, g, p.M, full, p.out_row, h_r, none_r, none_r, none_r, 1.f, 0.f);
+        x6_store_tile<0, TM, TN>(acc, cb, 0, g, p.M, full, p.out_row, h_r, none_r, none_r, none_r, 1.f, 0.f, osc1, hmax_all);
+        // (published together with y's at the end: the LDS is about to be reused for W1)
     }
 
     // ---- W1 fragments -> LDS, whole operand ([chunk][g][piece][Mp], Mp == BM): GEMM 2 runs without barriers
-    constexpr int W1_UNITS = (BM / 16) * 6 * BM;
+    constexpr int W1_UNITS = (BM / 16) * 2 * kX6P * BM;
     u32x4* const w1s = reinterpret_cast<u32x4*>(smem_raw);
     {
         const auto w1_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(u.wq1), 0, u.wq1_bytes, 0x00020000);
@@ -251,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
     __syncthreads();
 
     // ---- GEMM 2, one column tile at a time: B fragments straight from the accumulators of GEMM 1
+    float ymax = 0.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         f32x16 acc2[TM][1];
@@ -264,32 +299,38 @@ __global__ __launch_bounds__(256, 2) void unit_x6_kernel(const UnitP u) {
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = acc[tmh][tn][8 * hf + i];
-            u32x4 pk[3];
-            split8(v, u.slope2, pk);
-            bf16x8 bfr2[3], afr2[TM][3];
+            u32x4 pk[kX6P];
+            split8(v, u.slope2, h2sc, pk);
+            rh_x6_frag bfr2[kX6P], afr2[TM][kX6P];
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
+            for (int s3 = 0; s3 < kX6P; ++s3) {
                 // lane (j, 0) holds channels {0..3, 8..11} of the block, lane (j, 1) {4..7, 12..15}: exchanging the second
                 // pair of dwords of the lower half-wave with the first pair of the upper one gives 8g .. 8g+7 per lane
                 auto r0 = __builtin_amdgcn_permlane32_swap(pk[s3][0], pk[s3][2], false, false);
                 auto r1 = __builtin_amdgcn_permlane32_swap(pk[s3][1], pk[s3][3], false, false);
                 u32x4 f;
                 f[0] = r0[0]; f[2] = r0[1]; f[1] = r1[0]; f[3] = r1[1];
-                bfr2[s3] = __builtin_bit_cast(bf16x8, f);
+                bfr2[s3] = __builtin_bit_cast(rh_x6_frag, f);
             }
-            const u32x4* al = w1s + (b * 6 + g * 3) * BM + j;
+            const u32x4* al = w1s + (b * 2 * kX6P + g * kX6P) * BM + j;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) afr2[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+                for (int s3 = 0; s3 < kX6P; ++s3) afr2[tm][s3] = __builtin_bit_cast(rh_x6_frag, al[s3 * BM + tm * 32]);
 #pragma unroll
             for (int q = 0; q < RH_X6_NPROD; ++q)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    acc2[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr2[tm][SA[q]], bfr2[SB[q]], acc2[tm][0], 0, 0, 0);
+                    acc2[tm][0] = RH_X6_MFMA(afr2[tm][SA[q]], bfr2[SB[q]], acc2[tm][0]);
         }
         const unsigned cb1[1] = {cb[tn]};
-        x6_store_tile<4, TM, 1>(acc2, cb1, 0, g, p.M, full, p.out_row, y_r, none_r, x_r, none_r, 1.f, 0.f);
+        x6_store_tile<4, TM, 1>(acc2, cb1, 0, g, p.M, full, p.out_row, y_r, none_r, x_r, none_r, 1.f, 0.f, osc2, ymax);
+    }
+    if (RH_X6_F16 && (p.out_range || u.h_range)) {      // uniform; W1's LDS image is dead after a barrier
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);
+        if (p.out_range) rh_range_publish(p.out_range, ymax, blockIdx.x, red);
+        if (u.h_range) rh_range_publish(u.h_range, hmax_all, blockIdx.x + 5u, red + 4);
     }
 }
 
@@ -322,7 +363,7 @@ int fill_unit(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1, UnitP* u, size
     if (p.x6_mode != 1 || p1.x6_mode != 1 || p.nphase != 1) return RH_ERR_UNSUPPORTED;
     const int tm = p.M / 32;
     if (!rh_conv_x6_plan_fixed(p, tm, 2, 1, lds, grid)) return RH_ERR_UNSUPPORTED;
-    const size_t w1_bytes = (size_t)(p.M / 16) * 6 * p.M * 16;
+    const size_t w1_bytes = (size_t)(p.M / 16) * 2 * kX6P * p.M * 16;
     if (w1_bytes > *lds) *lds = w1_bytes;
     if (*lds > 160 * 1024 || (unsigned long long)p1.wq_bytes < w1_bytes) return RH_ERR_UNSUPPORTED;
     u->wq1_bytes = p1.wq_bytes;
@@ -341,6 +382,8 @@ extern "C" int rh_residual_unit_fused(const rh_conv1d_desc* d3, const rh_conv1d_
     UnitP u{};
     size_t lds = 0;
     dim3 grid;
+    static const unsigned any_range[kRangeWords] = {};
+    u.c.in_range = any_range;            // planning only
     return fill_unit(d3, d1, &u, &lds, &grid) == RH_OK ? 1 : 0;
 }
 
@@ -354,11 +397,17 @@ extern "C" int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1
     UnitP u{};
     size_t lds = 0;
     dim3 grid;
+    const unsigned* x_range = nullptr;
+    unsigned *y_range = nullptr, *h_range = nullptr;
+    rh_take_ranges(nullptr, &x_range, &y_range, &h_range);
+    RH_REQUIRE(!RH_X6_F16 || x_range, RH_ERR_INVALID, "residual_unit_fwd: the f16 kernels need the input's range slot (rh_x6_set_ranges)");
+    u.c.in_range = x_range;
     if (int e = fill_unit(d3, d1, &u, &lds, &grid)) {
         rh_set_error("residual_unit_fwd: geometry not fusable");
         return e;
     }
     ConvP& p = u.c;
+    p.in_range = x_range; p.out_range = y_range; u.h_range = h ? h_range : nullptr;
     RH_REQUIRE((((uintptr_t)wp3_fwd | (uintptr_t)wp1_fwd) & 15) == 0 && ((uintptr_t)x & 3) == 0, RH_ERR_INVALID,
                "residual_unit_fwd: misaligned operand");
     p.in = x; p.wp = wp3_fwd; p.out = y; p.bias = nullptr; p.add = x; p.mul_src = nullptr;
@@ -366,6 +415,8 @@ extern "C" int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1
     p.in_alpha = nullptr; p.mul_alpha = nullptr;
     p.in_bytes = (unsigned)(4ull * p.B * p.C * (unsigned long long)p.in_row);
     u.wq1 = reinterpret_cast<const unsigned*>(wp1_fwd + (long)(uintptr_t)u.wq1);
+    p.w_range = p.wq + p.wq_bytes / 4;
+    u.w1_range = u.wq1 + u.wq1_bytes / 4;
     u.h_out = h;
     auto go = [&](auto kern) {
         static std::once_flag once;

@@ -252,6 +252,10 @@ class RAVE(nn.Module):
         # all weight-normalised convs: weight norm + MFMA repack refreshed in two launches (plumbing;
         # the reference's weight_norm pre-hooks do the same work layer by layer)
         if batch.is_cuda:
+            # a fresh zeroed pool of range slots for this step's activations (ops.range_reset: one fill launch; recorded into
+            # a hipGraph it re-zeroes them at every replay)
+            from . import ops as _ops
+            _ops.range_reset(batch.device)
             # the discriminator only runs (and only then normalises its weights) in phase 2
             self.prepare_weights(with_discriminator=bool(self.warmed_up))
         x_raw = batch

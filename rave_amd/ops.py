@@ -6,6 +6,7 @@ There is no eager/PyTorch fallback: a missing library or a non-zero return code 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -242,23 +243,90 @@ def _ws(nbytes: int, device) -> Optional[Tensor]:
     return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes > 0 else None
 
 
+# ---- range slots of the f16 matrix-core kernels (include/rave_hip.h: rh_x6_set_ranges; csrc/common.hpp: RH_X6_F16) ------------
+# The x6 kernels scale every activation operand by a power of two derived from the TENSOR's max |x|.  That maximum travels with
+# the tensor as a "range slot" (kRangeWords uint32 in device memory): the kernel that produces a tensor leaves it there
+# (epilogue atomicMax: no extra pass), and the tensor OBJECT carries the slot as an attribute together with its version
+# counter.  A tensor without a (current) slot -- produced by a torch op, a view, modified in place -- gets one from a pass of
+# rh_amax_f32 the first time a convolution consumes it.  Slots come from a zeroed pool; RAVE.training_step takes a fresh pool per
+# step (range_reset: one fill launch -- recorded into a hipGraph it re-zeroes the slots at every replay, so a replayed step
+# computes the same scales as an eager one).
+_RANGES = L.lib.rh_x6_uses_ranges() == 1
+_RANGE_WORDS = L.lib.rh_x6_range_words()
+_RANGE_SLOTS = 1024
+_RANGE_POOLS = {}        # device -> [pool, cursor, previous pool (kept alive: a side stream may still read it)]
+
+
+def range_reset(device=None) -> None:
+    """Start a fresh zeroed slot pool (call at the start of a step; mandatory inside a hipGraph capture)."""
+    if not _RANGES:
+        return
+    for dev in ([device] if device is not None else list(_RANGE_POOLS)):
+        st = _RANGE_POOLS.get(dev)
+        prev = st[0] if st else None
+        _RANGE_POOLS[dev] = [torch.zeros(_RANGE_SLOTS * _RANGE_WORDS, device=dev, dtype=torch.int32), 0, prev]
+
+
+def _ranges_on() -> bool:
+    return _RANGES and os.environ.get("RH_CONV_X6", "1") != "0"
+
+
+def _new_range(device) -> Tensor:
+    st = _RANGE_POOLS.get(device)
+    if st is None or st[1] >= _RANGE_SLOTS:
+        range_reset(device)
+        st = _RANGE_POOLS[device]
+    i = st[1]
+    st[1] = i + 1
+    return st[0][i * _RANGE_WORDS:(i + 1) * _RANGE_WORDS]
+
+
+def _attach_range(t: Optional[Tensor], slot: Optional[Tensor]) -> None:
+    if t is not None and slot is not None:
+        t._rh_range = (slot, t._version)
+
+
+def _range_of(t: Tensor, s) -> Tensor:
+    """The range slot of ``t``: the one its producer left, else computed now (one pass over ``t`` on stream ``s``)."""
+    r = getattr(t, "_rh_range", None)
+    if r is not None and r[1] == t._version and r[0].device == t.device:
+        return r[0]
+    slot = _new_range(t.device)
+    L.check(L.lib.rh_amax_f32(L.ptr(t), t.numel(), L.ptr(slot), s), "amax")
+    _attach_range(t, slot)
+    return slot
+
+
 def _fwd(d, x, wp, bias, alpha, residual, y, s):
     _log_plan(d, 0, bias is not None, residual is not None)
     ws = _ws(L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)), y.device)
+    rin = rout = None
+    if _ranges_on():
+        rin, rout = _range_of(x, s), _new_range(y.device)
 
-    def run(out):
+    def run(out, ranges=True):
+        if ranges and rin is not None:
+            L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(rout), None)
         return L.lib.rh_conv1d_fwd_f32(C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(out),
                                        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s)
 
     rc = _launch("conv_fwd", d, lambda: run(y), bias is not None, residual is not None)
     if rc == 0:
-        _shadow("fwd", d, lambda o: run(o[0]), [y])
+        _attach_range(y, rout)
+        _shadow("fwd", d, lambda o: run(o[0], False), [y])
     return rc
 
 
 def _unit_fwd(d3, d1, x, wp3, wp1, h, y, s):
     """Fused Residual(DilatedUnit) forward (rh_residual_unit_fwd_f32); ``h`` None = inference (never written)."""
+    rin = ry = rh = None
+    if _RANGES:
+        rin, ry = _range_of(x, s), _new_range(x.device)
+        rh = _new_range(x.device) if h is not None else None
+
     def run(o_y, o_h):
+        if rin is not None:
+            L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(ry), L.ptr(rh))
         return L.lib.rh_residual_unit_fwd_f32(C.byref(d3), C.byref(d1), L.ptr(x), L.ptr(wp3), L.ptr(wp1), L.ptr(o_h), L.ptr(o_y), s)
 
     if _PLAN_LOG is not None:
@@ -269,6 +337,9 @@ def _unit_fwd(d3, d1, x, wp3, wp1, h, y, s):
         f3, b3 = _conv_cost(d3)
         f1, b1 = _conv_cost(d1)
         rc = _timed("conv_fwd[x6]", f3 + f1, b3 + b1, lambda: run(y, h))
+    if rc == 0:
+        _attach_range(y, ry)
+        _attach_range(h, rh)
     if rc == 0 and _SHADOW is not None:
         # the two-launch path on the exact-f32 kernels, same operands
         h2, y2 = torch.empty_like(x), torch.empty_like(x)
@@ -290,14 +361,20 @@ def _unit_fwd(d3, d1, x, wp3, wp1, h, y, s):
 def _dgrad(d, dy, wp, x, alpha, add, dx, s):
     _log_plan(d, 1, False, add is not None)
     ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
+    rin = rout = None
+    if _ranges_on():
+        rin, rout = _range_of(dy, s), _new_range(dx.device)
 
-    def run(out):
+    def run(out, ranges=True):
+        if ranges and rin is not None:
+            L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(rout), None)
         return L.lib.rh_conv1d_bwd_data_f32(C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(out),
                                             L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s)
 
     rc = _launch("conv_dgrad", d, lambda: run(dx), False, add is not None)
     if rc == 0:
-        _shadow("dgrad", d, lambda o: run(o[0]), [dx])
+        _attach_range(dx, rout)
+        _shadow("dgrad", d, lambda o: run(o[0], False), [dx])
     return rc
 
 
@@ -483,14 +560,22 @@ class _OnSide:
         return False
 
 
+def _arm_wgrad_ranges(dy, x, s) -> None:
+    """Range slots of both operands for the next weight-gradient call (the f16 weight-gradient kernel converts both)."""
+    if _RANGES and os.environ.get("RH_WGRAD_X6", "1") != "0":
+        L.lib.rh_x6_set_ranges(L.ptr(_range_of(dy, s)), L.ptr(_range_of(x, s)), None, None)
+
+
 def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s):
     def run(o_dw, o_db):
+        _arm_wgrad_ranges(dy, x, s)
         return L.lib.rh_conv1d_bwd_weight_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(o_dw), L.ptr(o_db), L.ptr(ws),
                                               nbytes, s)
 
     rc = _launch("conv_wgrad", d, lambda: run(dw, db))
     if rc == 0 and _SHADOW is not None:
         def run_exact(o):
+            L.lib.rh_x6_set_ranges(None, None, None, None)
             # the exact-f32 kernels plan their own K slices: their scratch is sized under THEIR plan (it used to fit into the
             # bf16x6 path's by accident, while that path cut K into twice as many slices)
             nb2 = L.lib.rh_conv1d_workspace_bytes(C.byref(d))
@@ -598,6 +683,7 @@ def _wgrad_wn(d, dy, x, alpha, dw, db, v, g, norms, ws, nbytes, s, slot_v=None, 
         if len(_WN_PENDING) >= _WN_BATCH_MAX:      # (we are on the side stream here: the batch runs beside the data-gradient chain)
             _flush_wn_pending(s)
         return dv, dg
+    _arm_wgrad_ranges(dy, x, s)
     L.check(L.lib.rh_conv1d_bwd_weight_wn_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(v), L.ptr(g), L.ptr(norms),
                                               L.ptr(dw), L.ptr(dv), L.ptr(dg), L.ptr(db), L.ptr(ws), nbytes, s),
             "conv1d_bwd_weight_wn")
@@ -626,6 +712,7 @@ class _ConvFn(torch.autograd.Function):
         L.check(_fwd(d, x, wp_f, bias, alpha, residual, y, s), "conv1d_fwd")
         ctx.save_for_backward(x, wp_b, alpha, weight if g is not None else None, g, norms,
                               y if geom.out_act != ACT_NONE else None)
+        ctx.x_range = getattr(x, "_rh_range", None)
         ctx.d = d
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -635,6 +722,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wp_b, alpha, v, g, norms, y_act = ctx.saved_tensors
+        if ctx.x_range is not None and getattr(x, "_rh_range", None) is None:
+            x._rh_range = ctx.x_range          # (the saved tensor may come back as a new object)
         d = ctx.d
         dref = C.byref(d)
         dy = _chk(dy, "dy")
@@ -753,11 +842,17 @@ class _ResidualUnitFn(torch.autograd.Function):
                               w1 if g1w is not None else None, g1w, n1)
         ctx.d3, ctx.d1 = d3, d1
         ctx.w3shape, ctx.w1shape = tuple(w3.shape), tuple(w1.shape)
+        ctx.x_range = getattr(x, "_rh_range", None)
+        ctx.h_range = getattr(h, "_rh_range", None) if h is not None else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, h, wp3b, wp1b, alpha0, alpha2, v3, g3w, n3, v1, g1w, n1 = ctx.saved_tensors
+        if ctx.x_range is not None and getattr(x, "_rh_range", None) is None:
+            x._rh_range = ctx.x_range
+        if ctx.h_range is not None and getattr(h, "_rh_range", None) is None:
+            h._rh_range = ctx.h_range
         d3, d1 = ctx.d3, ctx.d1
         r3, r1 = C.byref(d3), C.byref(d1)
         dy = _chk(dy, "dy")

@@ -30,25 +30,29 @@ def test_descriptor_queries_and_errors():
     from rave_amd import _lib as L
     d = L.ConvDesc(batch=32, c_in=96, c_out=96, l_in=4096, l_out=4096, kernel=3, stride=1, dilation=9,
                    pad_left=9, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
-    # K in blocks of 16: f32 operand + the bf16x6 section (3 x 2 bytes per weight)
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d), 0) == 3 * 96 * 96 * 5 // 2
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d), 1) == 3 * 96 * 96 * 5 // 2
+    # K in blocks of 16: f32 operand + the x6 section (P pieces x 2 bytes per weight: P = 2 f16 pieces in the product build,
+    # 3 bf16 pieces in the comparison build) + the 16-byte range record behind the fragments
+    P = 2 if L.lib.rh_x6_uses_ranges() else 3
+    n = 3 * 96 * 96
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d), 0) == n + n * P // 2 + 4
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d), 1) == n + n * P // 2 + 4
     d0 = L.ConvDesc(batch=32, c_in=96, c_out=192, l_in=4096, l_out=1024, kernel=8, stride=4, dilation=1,
                     pad_left=3, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
     # strided: phase-interleaved octets (forward); the data gradient carries two bf16x6 sections of the same size
     # (per-phase taps and the "virtual rows" form with contiguous output runs, chosen per launch)
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 0) == 8 * 96 * 192 * 5 // 2
-    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 1) == 8 * 192 * 96 * 4
+    n = 8 * 96 * 192
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 0) == n + n * P // 2 + 4
+    assert L.lib.rh_conv1d_packed_floats(C.byref(d0), 1) == n + 2 * (n * P // 2) + 4
     # transposed forward: same two sections (per output phase + virtual rows); its data gradient is a strided gather
     up = L.ConvDesc(batch=32, c_in=192, c_out=96, l_in=1024, l_out=4096, kernel=8, stride=4, dilation=1,
                     pad_left=2, transposed=1, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
-    assert L.lib.rh_conv1d_packed_floats(C.byref(up), 0) == 8 * 192 * 96 * 4
-    assert L.lib.rh_conv1d_packed_floats(C.byref(up), 1) == 8 * 192 * 96 * 5 // 2
+    assert L.lib.rh_conv1d_packed_floats(C.byref(up), 0) == n + 2 * (n * P // 2) + 4
+    assert L.lib.rh_conv1d_packed_floats(C.byref(up), 1) == n + n * P // 2 + 4
     # k = 5, stride 4 (period discriminators): phases carry 2 / 1 / 1 / 1 taps, the virtual-row section pads them to 2
     mpd = L.ConvDesc(batch=128, c_in=96, c_out=192, l_in=8192, l_out=2048, kernel=5, stride=4, dilation=1,
                      pad_left=2, transposed=0, groups=1, inner=1, in_valid=0, act=1, act_slope=0.2)
     n32 = 5 * 192 * 96
-    assert L.lib.rh_conv1d_packed_floats(C.byref(mpd), 1) == n32 + n32 * 3 // 2 + (192 // 16) * 2 * 6 * (96 * 4) * 4
+    assert L.lib.rh_conv1d_packed_floats(C.byref(mpd), 1) == n32 + n32 * P // 2 + (192 // 16) * 2 * (2 * P) * (96 * 4) * 4 + 4
     d1 = L.ConvDesc(batch=2, c_in=1, c_out=96, l_in=4096, l_out=1024, kernel=15, stride=4, dilation=1,
                     pad_left=7, transposed=0, groups=1, inner=1, in_valid=0, act=0, act_slope=0.0)
     assert L.lib.rh_conv1d_packed_floats(C.byref(d1), 0) == 15 * 1 * 96       # C*stride % 16 != 0: f32 operand only

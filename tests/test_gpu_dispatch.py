@@ -264,9 +264,13 @@ def test_fused_residual_unit_is_bit_identical_to_the_two_launch_path(dev, case):
         unsplit = unsplit and out[0] == 1 and out[4] == 1
     fused = run(True)
     split = run(True, RH_UNIT_FUSED=0)
-    for a, b in zip(fused, split):
-        if unsplit:
-            assert torch.equal(a, b)
+    # f16 build (round 6): the fused launch scales its in-register intermediate by a BOUND on max |h| (it cannot know the
+    # maximum before it has every tile), the two-launch path by the measured maximum: h and all gradients stay bit-identical,
+    # y agrees to the last bits of the two-piece representation (<= 1e-6) instead of exactly
+    f16 = Lb.lib.rh_x6_uses_ranges() == 1
+    for i, (a, b) in enumerate(zip(fused, split)):
+        if unsplit and not (f16 and i == 0):
+            assert torch.equal(a, b), i
         else:
             assert rel_l2(a, b) < 1e-6
     (y_ng,) = run(False)

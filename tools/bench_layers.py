@@ -57,10 +57,18 @@ for (name, ci, co, lin, k, st, dil, pl, pr, tr, act) in layers:
     ws = torch.empty(max(nws, 4) // 4, device=dev)
     nf = L.lib.rh_conv1d_fwd_workspace_bytes(r); nd = L.lib.rh_conv1d_bwd_data_workspace_bytes(r)
     wsf = torch.empty(max(nf, 4) // 4, device=dev); wsd = torch.empty(max(nd, 4) // 4, device=dev)
+    # range slots (f16 build, include/rave_hip.h: rh_x6_set_ranges): the inputs' are filled once, the outputs' are written by
+    # every launch as in the training step (never re-zeroed here: atomicMax of the same values)
+    use_r = L.lib.rh_x6_uses_ranges() == 1
+    sl = torch.zeros(4, L.lib.rh_x6_range_words(), device=dev, dtype=torch.int32)
+    if use_r:
+        L.check(L.lib.rh_amax_f32(L.ptr(x), x.numel(), L.ptr(sl[0]), s))
+        L.check(L.lib.rh_amax_f32(L.ptr(dy), dy.numel(), L.ptr(sl[1]), s))
+    arm = (lambda a, b, o: L.lib.rh_x6_set_ranges(L.ptr(a), L.ptr(b), L.ptr(o), None) and 0) if use_r else (lambda a, b, o: 0)
     fns = [
-        lambda: L.lib.rh_conv1d_fwd_f32(r, L.ptr(x), L.ptr(wpf), None, None, None, L.ptr(y), L.ptr(wsf), nf, s),
-        lambda: L.lib.rh_conv1d_bwd_data_f32(r, L.ptr(dy), L.ptr(wpb), L.ptr(x), None, None, L.ptr(dx), L.ptr(wsd), nd, s),
-        lambda: L.lib.rh_conv1d_bwd_weight_f32(r, L.ptr(dy), L.ptr(x), None, L.ptr(dw), None, L.ptr(ws), nws, s),
+        lambda: arm(None, sl[0], sl[2]) or L.lib.rh_conv1d_fwd_f32(r, L.ptr(x), L.ptr(wpf), None, None, None, L.ptr(y), L.ptr(wsf), nf, s),
+        lambda: arm(None, sl[1], sl[3]) or L.lib.rh_conv1d_bwd_data_f32(r, L.ptr(dy), L.ptr(wpb), L.ptr(x), None, None, L.ptr(dx), L.ptr(wsd), nd, s),
+        lambda: arm(sl[1], sl[0], None) or L.lib.rh_conv1d_bwd_weight_f32(r, L.ptr(dy), L.ptr(x), None, L.ptr(dw), None, L.ptr(ws), nws, s),
     ]
     flop = 2.0 * B * co * ci * k * (lin if tr else lout)
     res = []
@@ -81,7 +89,7 @@ for (name, ci, co, lin, k, st, dil, pl, pr, tr, act) in layers:
         # dgrad on the current stream and wgrad on a side stream at the same time (both only need dy and x)
         side = torch.cuda.Stream()
         s2 = side.cuda_stream
-        fw2 = lambda: L.lib.rh_conv1d_bwd_weight_f32(r, L.ptr(dy), L.ptr(x), None, L.ptr(dw), None, L.ptr(ws), nws, s2)
+        fw2 = lambda: arm(sl[1], sl[0], None) or L.lib.rh_conv1d_bwd_weight_f32(r, L.ptr(dy), L.ptr(x), None, L.ptr(dw), None, L.ptr(ws), nws, s2)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 5

@@ -95,16 +95,31 @@ for (name, ci, co, lin, k, st, dil, pl, pr, tr, act, b, inner) in layers:
     L.check(L.lib.rh_conv1d_pack_f32(r, L.ptr(w), L.ptr(wpf), L.ptr(wpb), s))
     out = {}
     tim = {}
+    # range slots (f16 build): the inputs' from rh_amax_f32, the outputs' are left by the launch and checked below
+    RW = L.lib.rh_x6_range_words()
+    use_r = L.lib.rh_x6_uses_ranges() == 1
+    slots = torch.zeros(4, RW, device=dev, dtype=torch.int32)
+    if use_r:
+        L.check(L.lib.rh_amax_f32(L.ptr(x), x.numel(), L.ptr(slots[0]), s))
+        L.check(L.lib.rh_amax_f32(L.ptr(dy), dy.numel(), L.ptr(slots[1]), s))
     for mode in ("0", "1"):
         os.environ["RH_CONV_X6"] = mode
         nf = L.lib.rh_conv1d_fwd_workspace_bytes(r); nd = L.lib.rh_conv1d_bwd_data_workspace_bytes(r)
         wsf = torch.empty(max(nf, 4) // 4, device=dev); wsd = torch.empty(max(nd, 4) // 4, device=dev)
         y = torch.full(ys, float("nan"), device=dev)
         dx = torch.full(xs, float("nan"), device=dev)
-        ff = lambda: L.lib.rh_conv1d_fwd_f32(r, L.ptr(x), L.ptr(wpf), L.ptr(bias), None, L.ptr(res), L.ptr(y), L.ptr(wsf), nf, s)
-        fd = lambda: L.lib.rh_conv1d_bwd_data_f32(r, L.ptr(dy), L.ptr(wpb), L.ptr(x), None, L.ptr(addg), L.ptr(dx), L.ptr(wsd), nd, s)
+        arm = use_r and mode == "1"
+        ff = lambda: (arm and L.lib.rh_x6_set_ranges(None, L.ptr(slots[0]), L.ptr(slots[2]), None)) or L.lib.rh_conv1d_fwd_f32(r, L.ptr(x), L.ptr(wpf), L.ptr(bias), None, L.ptr(res), L.ptr(y), L.ptr(wsf), nf, s)
+        fd = lambda: (arm and L.lib.rh_x6_set_ranges(None, L.ptr(slots[1]), L.ptr(slots[3]), None)) or L.lib.rh_conv1d_bwd_data_f32(r, L.ptr(dy), L.ptr(wpb), L.ptr(x), None, L.ptr(addg), L.ptr(dx), L.ptr(wsd), nd, s)
         tim[mode] = (timed(ff), timed(fd))
         out[mode] = (y.clone(), dx.clone())
+    if use_r:      # the published output ranges must cover the outputs (and not by much more than a bias)
+        for nm, t_, sl in (("y", out["1"][0], slots[2]), ("dx", out["1"][1], slots[3])):
+            pub = float(sl.view(torch.float32).max())
+            true = float(t_.abs().max())
+            if not (pub >= true and pub <= true + 8.0):
+                print(f"   RANGE SLOT WRONG for {nm}: published {pub} true {true}")
+                worst = float("inf")
     ef, ed = rel(out["1"][0], out["0"][0]), rel(out["1"][1], out["0"][1])
     if not (ef == ef and ed == ed):
         ef = ed = float("inf")
