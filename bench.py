@@ -31,11 +31,23 @@ V2_FWD_ACT_BYTES_PER_CLIP = 83_673_088
 V2_WEIGHT_BYTES = 126_123_072
 HBM_PEAK = 8.0e12          # B/s   MI355X_MICROARCH.md chip-level parameters
 F32_MFMA_PEAK = 157.3e12   # FLOP/s (f32-input MFMA == f32 vector peak)
-X6_MFMA_PEAK = 2.5e15 / 6  # FLOP/s f32-equivalent of the bf16 matrix cores at 6 MFMAs per product block (conv_x6)
-# what a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on this part with random operands: 20.1 ns per MFMA and
-# SIMD (one wave per SIMD; 17.9 with two) -- the chip is POWER-limited there, the shader clock reads 1.64 GHz instead of
-# 2.4 (tools/probe/mfma_clock.hip, profiles/round4_probe_mfma_clock.txt)
-X6_MFMA_SUSTAINED = 32768 * 1024 / 17.9e-9 / 6
+# FLOP/s f32-equivalent of the 16-bit matrix cores (2.5 PF dense) for the x6 kernels.  Round 6 (the product build, RH_X6_F16 = 1):
+# two f16 pieces per operand, THREE v_mfma_f32_32x32x16_f16 per product block -> 2.5 PF / 3 = 833 TFLOP/s; the comparison
+# build (rounds 2-5): three bf16 pieces, SIX products -> 417.  main() picks by what the loaded library says.
+X6_PRODUCTS = 3
+X6_MFMA_PEAK = 2.5e15 / 3
+# what a loop of nothing but these MFMAs sustains on this part with random operands (two waves per SIMD): the chip is
+# POWER-limited there, the shader clock reads ~1.6 GHz instead of 2.4 -- bf16: 17.9 ns per MFMA and SIMD
+# (tools/probe/mfma_clock.hip, profiles/round4_probe_mfma_clock.txt), f16: 19.5 ns (tools/probe/f16x3.hip,
+# profiles/round6_probe_f16x3.txt: the f16 multipliers draw ~9 % more)
+X6_MFMA_SUSTAINED = 32768 * 1024 / 19.5e-9 / 3
+
+
+def _set_x6_mode(f16: bool) -> None:
+    global X6_PRODUCTS, X6_MFMA_PEAK, X6_MFMA_SUSTAINED
+    X6_PRODUCTS = 3 if f16 else 6
+    X6_MFMA_PEAK = 2.5e15 / X6_PRODUCTS
+    X6_MFMA_SUSTAINED = 32768 * 1024 / (19.5e-9 if f16 else 17.9e-9) / X6_PRODUCTS
 
 
 def _cpu_point(batch: int, threads: int, n_signal: int) -> None:
@@ -198,7 +210,7 @@ def _pmc_traffic(kernel_name):
     collected on; a different library is loaded now -> traffic null + a note (the figure would silently be stale)."""
     fam = {"conv_x6_kernel": "conv_x6(fwd+dgrad)", "wgrad_x6_kernel": "wgrad_x6", "wgrad_dma_kernel": "wgrad_f32",
            "conv_igemm_dma_kernel": "conv_f32(fwd+dgrad)"}.get(kernel_name)
-    for name in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json"):
+    for name in ("round6_pmc_traffic.json", "round5_pmc_traffic.json", "round4_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -217,20 +229,55 @@ def _pmc_traffic(kernel_name):
     return None, "no PMC summary committed"
 
 
-def x6_products_leg():
-    """SECONDARY keys forward_only_x3 / forward_only_x4: the forward leg on the 3- / 4-partial-product
-    measurement builds of the bf16 kernels (rave_amd/_var/, tools/x6_products.py; one subprocess per library).  Labelled
-    with their dtype; the headline and ``forward_only`` stay on the 6-product (f32-class) path."""
+def _forward_leg(batch: int, n_signal: int) -> None:
+    """Child process (``bench.py --forward-leg B,N`` with RAVE_HIP_LIB pointing at a library): the inference forward of the
+    north-star leg on that library; prints ``FORWARD_LEG {json}``."""
+    from rave_amd import _lib as L, model as M
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = M.build_v2().to(dev).train()
+    x = 0.3 * torch.randn(batch, 1, n_signal, generator=torch.Generator().manual_seed(1)).clamp(-1, 1).to(dev)
+    with torch.no_grad():
+        m.prepare_weights(reuse=True)
+
+        def once():
+            m.prepare_weights(reuse=True)
+            m.decode(m.encoder.reparametrize(m.encode(x))[0])
+            m.release_weights()
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            once()
+        e1.record()
+        torch.cuda.synchronize()
+    print("FORWARD_LEG " + json.dumps({"ms": e0.elapsed_time(e1) / 10, "library": os.path.basename(L.LIB_PATH),
+                                       "f16_pieces": int(L.lib.rh_x6_uses_ranges())}))
+
+
+def bf16x6_leg(batch: int, n_signal: int):
+    """SECONDARY key forward_only_bf16x6: the forward leg on the comparison build of the x6 kernels in their round 2-5 form
+    (three bf16 pieces per operand, six partial products: rave_amd/_var/librave_hip_bf16.so, RH_X6_F16 = 0), in its own
+    process -- what the round-6 change to two f16 pieces / three products bought, on the same box."""
     import subprocess
+    from rave_amd import build as B
+    lib = B.variant_lib()
+    if not os.path.exists(lib):
+        return {"forward_only_bf16x6": {"error": f"{lib} missing: python -m rave_amd.build --variant"}}
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "x6_products.py"), "--json"], capture_output=True,
-                           text=True, timeout=600)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("X6_PRODUCTS ")]
+        env = dict(os.environ, RAVE_HIP_LIB=lib)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--forward-leg", f"{batch},{n_signal}"], capture_output=True,
+                           text=True, timeout=300, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("FORWARD_LEG ")]
         if r.returncode != 0 or not line:
-            return {"forward_only_x_error": (r.stderr or r.stdout)[-400:]}
-        return json.loads(line[-1][len("X6_PRODUCTS "):])
+            return {"forward_only_bf16x6": {"error": (r.stderr or r.stdout)[-400:]}}
+        d = json.loads(line[-1][len("FORWARD_LEG "):])
+        d["dtype"] = "f32 as 3 bf16 pieces x 6 products (rounds 2-5)"
+        return {"forward_only_bf16x6": d}
     except Exception as e:                          # noqa: BLE001 -- secondary keys never break the headline
-        return {"forward_only_x_error": repr(e)}
+        return {"forward_only_bf16x6": {"error": repr(e)}}
 
 
 def main():
@@ -256,12 +303,16 @@ def main():
                          "hipStreamEndCapture on ROCm 7.2: see the note at use_graph)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-products-leg", action="store_true",
-                    help="skip the secondary forward_only_x3 / _x4 legs (3- / 4-partial-product measurement builds)")
+                    help="skip the secondary forward_only_bf16x6 leg (comparison build: 3 bf16 pieces, 6 products)")
+    ap.add_argument("--forward-leg", default=None, help=argparse.SUPPRESS)   # child process of bf16x6_leg()
     ap.add_argument("--cpu-point", default=None, help=argparse.SUPPRESS)      # child process of cpu_baseline()
     args = ap.parse_args()
     if args.cpu_point:
         b, thr, n = (int(v) for v in args.cpu_point.split(","))
         return _cpu_point(b, thr, n)
+    if args.forward_leg:
+        b, n = (int(v) for v in args.forward_leg.split(","))
+        return _forward_leg(b, n)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
@@ -294,7 +345,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from rave_amd import ddp, model as M, ops
+    from rave_amd import _lib as _L, ddp, model as M, ops
+    _set_x6_mode(_L.lib.rh_x6_uses_ranges() == 1)
 
     torch.manual_seed(0)
     n_ch = 1
@@ -455,8 +507,9 @@ def main():
         for kind, fl, by, kms, cms in rec:
             a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += by; a[3] += (kms if kms is not None else cms); a[4] += cms
-        # every launch is priced against the peak of the instruction it issues: conv_x6_kernel = exact f32 as six
-        # v_mfma_f32_32x32x16_bf16 per product block (2.5 PF / 6 = 417 TFLOP/s f32-equivalent); the f32-input MFMA
+        # every launch is priced against the peak of the instruction it issues: conv_x6_kernel = f32 as X6_PRODUCTS 16-bit
+        # MFMAs per product block (round 6: three v_mfma_f32_32x32x16_f16 -> 2.5 PF / 3 = 833 TFLOP/s f32-equivalent;
+        # comparison build: six bf16 ones -> 417); the f32-input MFMA
         # kernels (conv_igemm_dma_kernel forward / data gradient of the few geometries x6 does not take, and
         # wgrad_dma_kernel for the <= 96-row weight gradients on long sequences) = 157.3 TFLOP/s
         peak_of = lambda k: X6_MFMA_PEAK if k.endswith("[x6]") else F32_MFMA_PEAK
@@ -496,8 +549,16 @@ def main():
                            "weight-gradient branch on a second stream.  avg_call_ms = event bracket around the whole C-ABI "
                            "call: + the split-K finalize launch where the plan splits K, + event overhead",
             "note": "f32 in / f32 accumulate everywhere; peak = that of the instruction the kernel issues (conv_x6_kernel: "
-                    "every f32 split exactly into 3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block -> 2.5 PF / 6 = "
-                    "417 TFLOP/s f32-equivalent; f32-input MFMA kernels: 157.3)",
+                    + ("every f32 operand scaled by its tensor's power-of-two range and split into 2 f16 pieces, 3 "
+                       "v_mfma_f32_32x32x16_f16 per product block -> 2.5 PF / 3 = 833 TFLOP/s f32-equivalent"
+                       if X6_PRODUCTS == 3 else
+                       "every f32 split exactly into 3 bf16, 6 v_mfma_f32_32x32x16_bf16 per product block -> 2.5 PF / 6 = "
+                       "417 TFLOP/s f32-equivalent") + "; f32-input MFMA kernels: 157.3)",
+            "x6_products": X6_PRODUCTS,
+            "frac_vs_6_product_peak": fl / (ms * 1e-3) / (2.5e15 / 6),
+            "hbm_frac": by / (ms * 1e-3) / HBM_PEAK,
+            "bound_note": "arithmetic intensity of the family (algorithmic FLOP / algorithmic byte) vs the ridge of the issued "
+                          "instruction (peak FLOP/s / 8 TB/s): %.0f vs %.0f FLOP/B" % (fl / by, peak / HBM_PEAK),
         }
         out["kernels"] = {k: ({"launches_per_step": v[0] // reps, "ms_per_step": v[3] / reps, "call_ms_per_step": v[4] / reps,
                                "tflops": v[1] / (v[3] * 1e-3) / 1e12, "peak_tflops": v[5] / 1e12,
@@ -507,9 +568,9 @@ def main():
                                "algorithmic_TBps": v[2] / (v[3] * 1e-3) / 1e12, "peak_TBps": HBM_PEAK / 1e12,
                                "frac_of_hbm_peak": v[2] / (v[3] * 1e-3) / HBM_PEAK}) for k, v in byk.items()}
         out["roofline"]["mfma_note"] = ("frac is against the NOMINAL rate of the issued MFMA (2.4 GHz); under a pure "
-                                        "v_mfma_f32_32x32x16_bf16 load with random operands the part is power-limited: the shader "
-                                        "clock reads 1.64 GHz (s_memtime / wall) and one MFMA takes 20.1 ns per SIMD (17.9 with two "
-                                        "waves) = 0.67-0.75 of nominal; up to 2 independent VALU per MFMA gap cost nothing in wall "
+                                        "16-bit MFMA load with random operands the part is power-limited: the shader "
+                                        "clock reads ~1.6 GHz (s_memtime / wall) and one MFMA takes 17.9 (bf16) / 19.5 (f16) ns per "
+                                        "SIMD with two waves = 0.68-0.75 of nominal (tools/probe/f16x3.hip); up to 2 independent VALU per MFMA gap cost nothing in wall "
                                         "time, each further one ~1.2 ns (tools/probe/mfma_clock.hip, "
                                         "profiles/round4_probe_mfma_clock.txt).  frac_vs_sustained_mfma_rate prices the kernel "
                                         "against that measured rate")
@@ -552,7 +613,7 @@ def main():
                                "samples_per_s": args.batch * args.n_signal / t_fwd}
     if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_products_leg and args.config == "v2" \
             and args.batch == 32 and args.n_signal == 65536:
-        out.update(x6_products_leg())
+        out.update(bf16x6_leg(args.batch, args.n_signal))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "v2":
         out["cpu_baseline"] = cpu_baseline(args.n_signal)
     if use_ddp:

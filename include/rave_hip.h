@@ -171,7 +171,8 @@ int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1,
  * The "x6" kernels (conv_x6_kernel, unit_x6_kernel, wgrad_x6_kernel) compute exact-f32-class products on the f16 matrix cores:
  * every operand is scaled by a power of two that takes its TENSOR's largest magnitude into [2^14, 2^15) and split into two
  * f16 pieces (csrc/common.hpp).  The scale needs max |x| of each activation operand; it travels in a RANGE SLOT: an array of
- * rh_x6_range_words() uint32 in device memory, each the bit pattern of a non-negative float -- max |x| is the largest word (any
+ * rh_x6_range_words() uint32 in device memory (32 words in use, one per 128-byte line so that the producers' atomics do not
+ * serialise; the rest stays zero), each the bit pattern of a non-negative float -- max |x| is the largest word (any
  * upper bound within a factor of ~2^10 of it keeps f32 accuracy; a too SMALL value overflows f16: the slot must cover the
  * tensor).  rh_x6_set_ranges arms the slots of the NEXT rh_conv1d_fwd_f32 / rh_conv1d_bwd_data_f32 / rh_residual_unit_fwd_f32
  * / rh_conv1d_bwd_weight[_wn]_f32 call of this thread (consumed by that call, like rh_set_kernel_events):

@@ -58,7 +58,7 @@ void rh_take_ranges(const unsigned** a, const unsigned** b, unsigned** out, unsi
     rh_rng_out = rh_rng_out2 = nullptr;
 }
 extern "C" int rh_x6_uses_ranges(void) { return RH_X6_F16 ? 1 : 0; }
-extern "C" int rh_x6_range_words(void) { return kRangeWords; }
+extern "C" int rh_x6_range_words(void) { return kRangeSlotWords; }
 
 extern "C" int rh_event_create(void** ev) {
     RH_REQUIRE(ev, RH_ERR_INVALID, "event_create: null pointer");

@@ -96,10 +96,14 @@ typedef __bf16 rh_x6_frag __attribute__((ext_vector_type(8)));
 #endif
 constexpr int kX6P = RH_X6_NPIECE;             // pieces (16-byte fragments) stored per octet of 8 K values
 
-// A range slot: kRangeWords words, each the bit pattern of a non-negative float; the tensor's max |x| is the largest of them
-// (producers atomicMax their workgroups' maxima into word (workgroup id) % kRangeWords -- one hot word would serialise
-// thousands of atomics at the end of a launch).  Must be zero before the producer runs.
+// A range slot: kRangeWords words, ONE PER 128-BYTE LINE (kRangeStride words apart), each the bit pattern of a non-negative
+// float; the tensor's max |x| is the largest of them.  Producers atomicMax their workgroups' maxima into word
+// (workgroup id) % kRangeWords.  Agent-scope atomics are performed memory-side on this chip and serialise per LINE: 1024
+// workgroups publishing into 32 words of one line cost +5.4 us per launch, into 32 lines +0.4 us (tools/probe/atomic_fanin.hip,
+// profiles/round6_probe_atomic_fanin.txt).  Must be zero before the producer runs.
 constexpr int kRangeWords = 32;
+constexpr int kRangeStride = 32;
+constexpr int kRangeSlotWords = kRangeWords * kRangeStride;      // uint32 per slot (4 KB)
 // Power-of-two scale that takes a tensor with max |x| = float(bits) into [2^14, 2^15), as a float bit pattern; *inv_exp = the
 // biased exponent of its inverse.  Exponents are clamped to normal floats: tensors whose maximum is below 2^-111 lose
 // precision (their products underflow f32 anyway), Inf / NaN maxima scale like the largest finite float.
@@ -123,12 +127,12 @@ __host__ __device__ __forceinline__ unsigned rh_x6_unscale_bits(int inv_exp_a, i
 __device__ __forceinline__ unsigned rh_range_max(const unsigned* slot) {       // uniform (scalar loads)
     unsigned m = 0;
 #pragma unroll
-    for (int i = 0; i < kRangeWords; ++i) m = max(m, slot[i]);
+    for (int i = 0; i < kRangeWords; ++i) m = max(m, slot[i * kRangeStride]);
     return m;
 }
-// max |v| of the WORKGROUP (256 threads, every thread must call) -> ONE atomic on slot word `salt` % kRangeWords.  Agent-scope
-// atomics are performed memory-side on this chip, ~0.1 us each when they hit one address: 12 k per-wave atomics at the end of a
-// split-K finalize launch cost 60 us (measured, round 6) -- hence one per workgroup, spread over the words, from capped grids.
+// max |v| of the WORKGROUP (256 threads, every thread must call) -> ONE atomic on slot word `salt` % kRangeWords (12 k per-wave
+// atomics into one line at the end of a split-K finalize launch cost 60 us: measured, round 6 -- hence one per workgroup, one
+// line per word).
 // `red`: 4 floats of LDS nobody else touches any more.
 __device__ __forceinline__ void rh_range_publish(unsigned* slot, float amax_lane, unsigned salt, float* red) {
 #pragma unroll
@@ -138,7 +142,7 @@ __device__ __forceinline__ void rh_range_publish(unsigned* slot, float amax_lane
     if (threadIdx.x == 0) {
         float m = red[0];
         for (unsigned w = 1; w < (blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
-        atomicMax(slot + (salt % kRangeWords), __float_as_uint(m));
+        atomicMax(slot + (salt % kRangeWords) * kRangeStride, __float_as_uint(m));
     }
 }
 __device__ __forceinline__ float rh_absmax(float m, float v) {                 // max(m, |v|) as one v_max_f32

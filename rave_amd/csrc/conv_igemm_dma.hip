@@ -400,7 +400,7 @@ int finalize_launch(const ConvP& p, hipStream_t stream) {
                      (((uintptr_t)p.part | (uintptr_t)p.out | (uintptr_t)p.mul_src | (uintptr_t)p.add) & 15) == 0;
     const long items = vec ? total / 4 : total;
     long blocks = rh_cdiv64(items, 256);
-    if (p.out_range && blocks > 1024) blocks = 1024;       // one range atomic per workgroup (see the kernels)
+    if (p.out_range && blocks > 4096) blocks = 4096;       // one range atomic per workgroup (see the kernels)
     if (vec) hipLaunchKernelGGL(splitk_finalize4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, items);
     else hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, items);
     return rh_check_launch("conv_splitk_finalize");

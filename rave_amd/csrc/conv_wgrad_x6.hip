@@ -52,11 +52,7 @@ struct Wx6P {
     int off[kMaxTaps];
 };
 
-__device__ __forceinline__ u32x4 wx6_lds_read_b128_any(unsigned addr) {      // 16 bytes at any 2-byte alignment (1.4x the aligned cost)
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
+typedef u32x4 u32x4_u __attribute__((aligned(2)));      // 16 bytes at any 2-byte alignment: ds_read_b128 serves it at 1.4x the aligned cost
 
 // LeakyReLU (slope in [0, 1]; 1 = none) + split of 8 samples -> kX6P 16-byte fragments.  f16 build: the samples are scaled
 // by `sc` (power of two, from the operand's range slot) and split hi / lo with packed converts, ~5 VALU per sample; bf16 build:
@@ -129,7 +125,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* const a_st = reinterpret_cast<u32x4*>(smem_raw);              // [kKS][g][piece][BM]
     u32x4* const b_st = a_st + kKS * A_UNITS;                             // [kKS][g][piece][BN]   (PL: [piece][channel][position] bf16)
-    const unsigned b_img = (unsigned)(size_t)b_st;                        // LDS byte address of the plane image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,24 +302,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const Wx6P p) {
 #pragma unroll
                     for (int s3 = 0; s3 < kX6P; ++s3) afr[tm][s3] = __builtin_bit_cast(rh_x6_frag, al[s3 * BM + tm * 32]);
                 if constexpr (PL) {
-                    // the 8 positions 16 kb + 8 g .. + 7 of the column's channel image, shifted by its tap: an unaligned read.
-                    // One column tile at a time (three fragments in registers, not six): every accumulator still receives its
-                    // six products in the same order.
-                    const unsigned bo = b_img + (unsigned)((kb * 16 + g * 8) * 2);
+                    // the 8 positions 16 kb + 8 g .. + 7 of the column's channel image, shifted by its tap: a 16-byte LDS read at
+                    // 2-byte alignment.  Round 6: a plain C++ load through a 2-byte-aligned vector type -- the compiler emits
+                    // ds_read_b128 for it on gfx950, counts it (lgkmcnt) and schedules it like the aligned path's reads (round 5
+                    // issued it as inline asm and waited for every column tile with nothing else in flight).
+                    const unsigned char* bimg = reinterpret_cast<const unsigned char*>(b_st) + (kb * 16 + g * 8) * 2;
+                    rh_x6_frag bfr[2][kX6P];
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) {
-                        if (tn == 1 && !live2) break;                                   // wave-uniform
-                        u32x4 b0 = wx6_lds_read_b128_any(bo + bcolb[tn]), b1 = wx6_lds_read_b128_any(bo + bcolb[tn] + b_piece);
-                        u32x4 b2 = kX6P == 3 ? wx6_lds_read_b128_any(bo + bcolb[tn] + 2u * b_piece) : b1;
-                        // (the compiler does not count the asm reads: wait for everything LDS has in flight)
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2));
-                        const rh_x6_frag bf[3] = {__builtin_bit_cast(rh_x6_frag, b0), __builtin_bit_cast(rh_x6_frag, b1), __builtin_bit_cast(rh_x6_frag, b2)};
+                    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                        for (int q = 0; q < RH_X6_NPROD; ++q)
+                        for (int s3 = 0; s3 < kX6P; ++s3)
+                            bfr[tn][s3] = __builtin_bit_cast(rh_x6_frag, *reinterpret_cast<const u32x4_u*>(bimg + bcolb[tn] + (unsigned)s3 * b_piece));
 #pragma unroll
-                            for (int tm = 0; tm < TM; ++tm)
-                                acc[tm][tn] = RH_X6_MFMA(afr[tm][SA[q]], bf[SB[q]], acc[tm][tn]);
-                    }
+                    for (int q = 0; q < RH_X6_NPROD; ++q)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            acc[tm][0] = RH_X6_MFMA(afr[tm][SA[q]], bfr[0][SB[q]], acc[tm][0]);
+                            if (live2) acc[tm][1] = RH_X6_MFMA(afr[tm][SA[q]], bfr[1][SB[q]], acc[tm][1]);
+                        }
                 } else {
                     rh_x6_frag bfr[2][kX6P];
 #pragma unroll
@@ -429,8 +424,11 @@ bool plan_wx6(const WgradP& w, Wx6P* p, Wx6Plan* pl, const unsigned* r_range, co
     // plane mode (round 5, RH_WGRAD_X6_PLANES=1): stride-1 layers with several taps whose reach fits the image (<= 7 octets
     // per channel: the k = 3 units up to dilation 9 -- reach 18 --, the k = 7 stem).  Default: the per-tap conversion.
     {
-        const char* pe = getenv("RH_WGRAD_X6_PLANES");          // read per call (the tests compare both)
-        const bool on = pe && pe[0] == '1';                      // OPT-IN: measured slower, see the kernel's header comment
+        // Round 6 (compiler-visible unaligned reads, two f16 pieces): faster where the rows are few and the conversion dominates
+        // -- M <= 96: C = 96 k = 3 104 -> 89 us, stem / output layer +3 % -- slower from C = 192 on (C = 384 k = 3 59 -> 79 us):
+        // on by default for M <= 96, RH_WGRAD_X6_PLANES = 1 / 0 forces it everywhere / nowhere (read per call: tests).
+        const char* pe = getenv("RH_WGRAD_X6_PLANES");
+        const bool on = pe ? pe[0] == '1' : Mp <= 96;
         const int reach = w.maxoff - w.minoff;
         const int p8 = (32 + reach + 7) / 8;
         pl->planes = on && pl->tm >= 2 && w.is == 1 && w.T >= 2 && reach >= 0 && p8 <= 7 && 4l * (w.s_row + 64) * w.C * w.B < 0x7fffffffl;
@@ -497,7 +495,7 @@ void go(const Wx6P& p, const Wx6Plan& pl, hipStream_t stream) {
 int64_t rh_wgrad_x6_workspace(const WgradP& w) {
     Wx6P p;
     Wx6Plan pl{};
-    static const unsigned any_range[kRangeWords] = {};      // planning only: the answer does not depend on the slots
+    static const unsigned any_range[kRangeSlotWords] = {};      // planning only: the answer does not depend on the slots
     if (!plan_wx6(w, &p, &pl, any_range, any_range)) return -1;
     // partial weight tiles (Z > 1) + partial row sums for the fused bias gradient (always reserved)
     return (pl.Z > 1 ? (int64_t)pl.Z * w.M * w.C * w.T : 0) * (int64_t)sizeof(float) + (int64_t)pl.Z * w.M * (int64_t)sizeof(float);

@@ -224,7 +224,7 @@ bool rh_conv_x6_plan_fixed(ConvP& p, int tm, int tn, int wm, size_t* lds, dim3* 
 
 int64_t rh_conv_x6_workspace(ConvP p) {
     X6Plan pl{};
-    static const unsigned any_range[kRangeWords] = {};
+    static const unsigned any_range[kRangeSlotWords] = {};
     if (!p.in_range) p.in_range = any_range;           // planning only: the answer does not depend on the slot
     if (!plan_x6(p, &pl)) return -1;
     return pl.part_bytes;
@@ -234,7 +234,7 @@ int64_t rh_conv_x6_workspace(ConvP p) {
 // out = {tm, tn, wm, ksplit, input stride of the fragment layout, vs, workgroups}; false = the geometry does not take this path.
 bool rh_conv_x6_plan_query(ConvP p, int* out) {
     X6Plan pl{};
-    static const unsigned any_range[kRangeWords] = {};
+    static const unsigned any_range[kRangeSlotWords] = {};
     if (!p.in_range) p.in_range = any_range;
     if (!plan_x6(p, &pl)) return false;
     out[0] = pl.tm; out[1] = pl.tn; out[2] = pl.wm; out[3] = pl.ksplit;

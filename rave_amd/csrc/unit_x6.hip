@@ -382,7 +382,7 @@ extern "C" int rh_residual_unit_fused(const rh_conv1d_desc* d3, const rh_conv1d_
     UnitP u{};
     size_t lds = 0;
     dim3 grid;
-    static const unsigned any_range[kRangeWords] = {};
+    static const unsigned any_range[kRangeSlotWords] = {};
     u.c.in_range = any_range;            // planning only
     return fill_unit(d3, d1, &u, &lds, &grid) == RH_OK ? 1 : 0;
 }

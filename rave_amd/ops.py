@@ -253,7 +253,7 @@ def _ws(nbytes: int, device) -> Optional[Tensor]:
 # computes the same scales as an eager one).
 _RANGES = L.lib.rh_x6_uses_ranges() == 1
 _RANGE_WORDS = L.lib.rh_x6_range_words()
-_RANGE_SLOTS = 1024
+_RANGE_SLOTS = 512      # 4 KB each
 _RANGE_POOLS = {}        # device -> [pool, cursor, previous pool (kept alive: a side stream may still read it)]
 
 

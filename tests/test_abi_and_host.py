@@ -503,3 +503,16 @@ def test_table_entry_points_validate_their_host_tables_without_a_gpu():
     ai[0].n = 8                                                                       # no step counter
     assert L.lib.rh_adam_step_f32(ai, 1, addr, 0.5, 0.9, 1e-8, addr, None) != 0 and b"bad item" in L.lib.rh_last_error()
     assert L.lib.rh_conv1d_bwd_weight_wn_fused_launches() == 0
+
+
+def test_product_pqmf_filter_bank_is_bit_identical_to_the_reference_buffers():
+    """SURVEY section 8 rows a2-a4 (rave/pqmf.py:55-89,245-254: kaiser_filter -> get_prototype -> get_qmf_bank ->
+    center_pad_next_pow_2, polyphase weights): the buffers ``rave_amd.pqmf.CachedPQMF(100, 16)`` builds ON ITS OWN -- every
+    GPU parity test overwrites them with oracle / golden weights, so a scipy upgrade could silently change the product's
+    filters (VERDICT r5 weak #1c) -- against the reference's buffers in tests/golden/pqmf.pt (oracle/make_golden.py)."""
+    from rave_amd.pqmf import CachedPQMF
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "pqmf.pt"))
+    m = CachedPQMF(100, 16)
+    assert torch.equal(m.h, g["h"]) and torch.equal(m.hk, g["hk"])
+    assert torch.equal(m.forward_conv.weight.detach(), g["w_fwd"])
+    assert torch.equal(m.inverse_conv.weight.detach(), g["w_inv"])

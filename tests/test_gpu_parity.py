@@ -1094,7 +1094,11 @@ def test_gpu_batch_feed_matches_the_reference_transform_chain(dev):
         x = pcm[items[b]].astype(np.float32) / (2 ** 15 - 1)
         x = x[..., in_points[b]:in_points[b] + n]
         if angles[b] is not None:
-            bb, aa = D.pole_to_z_filter(angles[b], .99)
+            # the all-pass of rave/dataset.py:290-294 (pole_to_z_filter) restated HERE, not taken from the product
+            # (VERDICT r5 weak #1d): pole z0 = amplitude e^{i omega}, a = [1, -2 Re z0, |z0|^2], b = a reversed
+            z0 = .99 * np.exp(1j * angles[b])
+            aa = [1.0, -2.0 * float(np.real(z0)), float(abs(z0) ** 2)]
+            bb = [float(abs(z0) ** 2), -2.0 * float(np.real(z0)), 1.0]
             x = lfilter(bb, aa, x)
         x = x + noise[2 * b:2 * b + 2].astype(np.float64) / 2 ** 16
         ref = x.astype(np.float32)
@@ -1343,7 +1347,7 @@ def test_v2_full_width_with_the_fused_reparametrisation_gate_flips_counted(dev):
     1(a) explains its three tensors".  Here the gates are COUNTED (tests/gate_flips.py): every gradient outside the tight
     bound lies upstream of a LeakyReLU gate whose pre-activation changed sign against the fp64 evaluation, and stays within
     the few-flip bound; outputs keep the 1e-4 bar."""
-    from gate_flips import chain_flips, flips_downstream_by_param
+    from gate_flips import chain_flips, flip_allowance_by_param, flips_downstream_by_param
     g = {}
     m, sdr, ref, got = _full_width_grads(dev, 2, "1", reparam_fused="1", gates=g)
     assert rel_l2(got["x_mb"], ref["x_mb"]) < TOL_OP
@@ -1351,6 +1355,7 @@ def test_v2_full_width_with_the_fused_reparametrisation_gate_flips_counted(dev):
         assert rel_l2(got[k], ref[k]) < TOL_E2E, k
     flips, n_gates, worst_mag = chain_flips(g["log"], g["oracle64"])
     down = flips_downstream_by_param(g["log"], flips)
+    allow = flip_allowance_by_param(g["log"], flips)
     named = dict(m.named_parameters())
     outside, checked = [], 0
     for k, v in sdr.items():
@@ -1361,7 +1366,7 @@ def test_v2_full_width_with_the_fused_reparametrisation_gate_flips_counted(dev):
         tol = 1e-3 if k.endswith("weight_g") else 2e-4
         if err >= max(tol, 3.0 * ref_err):
             outside.append((k, err, ref_err, down[k]))
-        assert err < 5e-3, (k, err, ref_err)
+        assert err < max(tol, 3.0 * ref_err) + 3.0 * allow[k], (k, err, ref_err, allow[k])     # (flip-scaled: no fixed 5e-3)
         checked += 1
     print(f"fused reparametrisation: gate flips vs fp64 {sum(flips)} of {n_gates} (largest flipped |pre-activation| {worst_mag:.1e} x rms); "
           f"outside the tight bound: {[(k, '%.1e' % e, d) for k, e, _, d in outside]}")
@@ -1444,7 +1449,7 @@ def test_discrete_full_size_forward_backward_vs_oracle(dev, x6_mode):
         tol = 1e-3 if k.endswith("weight_g") else 2e-4
         if err >= max(tol, 3.0 * ref_err):
             outside.append((k, err, ref_err, down[k]))
-        assert err < min(max(tol, 3.0 * ref_err) + 3.0 * allow[k], 5e-3), (k, err, ref_err, allow[k])
+        assert err < max(tol, 3.0 * ref_err) + 3.0 * allow[k], (k, err, ref_err, allow[k])
         checked += 1
     print(f"discrete full size (RH_CONV_X6={x6_mode}): gate flips vs fp64 {sum(flips)} of {n_gates}; outside the tight bound: "
           f"{[(k, '%.1e' % e, d) for k, e, _, d in outside]}")
@@ -1567,12 +1572,14 @@ def test_v2_full_width_reference_golden(golden_dir, dev):
         O.rave_forward(g["x"].double(), sd64, cfg, g["eps"].double())
     flips, n_gates, worst_mag = chain_flips(gate_log, og.masks)
     down = flips_downstream_by_param(gate_log, flips)
+    from gate_flips import flip_allowance_by_param
+    allow = flip_allowance_by_param(gate_log, flips)
     print(f"gate flips vs the fp64 evaluation: {sum(flips)} of {n_gates} gate elements (largest flipped |pre-activation| "
           f"{worst_mag:.1e} x rms); outside the tight bound: {[(k, '%.1e' % e, down[k]) for k, e, _ in flipped]}")
     assert sum(flips) <= 1e-4 * n_gates and worst_mag < 1e-3
     for k, err, ref_err in flipped:
         assert down[k] >= 1, (k, err, ref_err, "no flipped gate downstream")
-        assert err < 5e-3, (k, err, ref_err)
+        assert err < max(2e-4, 3.0 * ref_err) + 3.0 * allow[k], (k, err, ref_err, allow[k])
 
 
 def _hinge_step_vs_oracle(dev, model, feats_ref_fn, xy, tol=5e-4):

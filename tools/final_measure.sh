@@ -1,16 +1,19 @@
-# end-of-round measurement batch (run on the GPU box through gpurun); outputs under $O (default gpurun_out/r5f/; copied into profiles/round5_*)
+# end-of-round measurement batch (run on the GPU box through gpurun); outputs under $O (default gpurun_out/r6f/; copied into profiles/round6_*)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=${O:-gpurun_out/r5f}; mkdir -p $O
+O=${O:-gpurun_out/r6f}; mkdir -p $O
 PARTS=${PARTS:-all}
 has() { [ "$PARTS" = all ] || echo " $PARTS " | grep -q " $1 "; }
 if has probes; then      # (binaries: bash tools/probe/build.sh in the build container)
   timeout 120 tools/probe/_var/mfma_clock > $O/probe_mfma_clock.txt 2>&1
   timeout 60 tools/probe/_var/tr_read > $O/probe_tr_read.txt 2>&1
   timeout 60 tools/probe/_var/lds_unaligned > $O/probe_lds_unaligned.txt 2>&1
+  timeout 60 tools/probe/_var/f16x3 > $O/probe_f16x3.txt 2>&1
+  timeout 60 tools/probe/_var/atomic_fanin > $O/probe_atomic_fanin.txt 2>&1
 fi
-if has products; then    # 3 / 4 bf16 partial products against the 6-product kernels and the CPU oracle (tools/x6_products.py)
-  timeout 600 python tools/x6_products.py --md $O/x6_products.md > $O/x6_products.log 2>&1
+if has bf16; then        # the comparison build (three bf16 pieces, six products: rave_amd/_var/librave_hip_bf16.so) on the same box
+  RAVE_HIP_LIB=$PWD/rave_amd/_var/librave_hip_bf16.so timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-products-leg < /dev/null > $O/bench_n1_bf16x6.log 2>&1
+  RAVE_HIP_LIB=$PWD/rave_amd/_var/librave_hip_bf16.so timeout 200 python tools/bench_layers.py < /dev/null > $O/layers_bf16x6.log 2>&1
 fi
 if has refstep; then     # the unmodified reference training_step on the drop-ins (needs tools/run_reference_step.sh stage)
   [ -d oracle/_ref/reference/rave ] && timeout 600 python tools/run_reference_step.py > $O/reference_step.log 2>&1
@@ -83,7 +86,7 @@ fi
 if has disc; then
   for w in v2 encodec descript; do N=32; [ $w = v2 ] && N=64; WHICH=$w N=$N timeout 300 python tools/bench_disc2d.py < /dev/null > $O/disc_$w.log 2>&1; done
 fi
-for f in bench_n1 bench_n1_eager bench_dist1 bench_gan bench_gan_skip bench_discrete bench_v3; do [ -f $O/$f.log ] && { echo "== $f"; grep "^{" $O/$f.log | tail -1 | cut -c1-330; }; done
+for f in bench_n1 bench_n1_bf16x6 bench_n1_eager bench_dist1 bench_gan bench_gan_skip bench_discrete bench_v3; do [ -f $O/$f.log ] && { echo "== $f"; grep "^{" $O/$f.log | tail -1 | cut -c1-330; }; done
 [ -f $O/layers.log ] && tail -2 $O/layers.log; [ -f $O/check_x6.log ] && tail -1 $O/check_x6.log; [ -f $O/pqmf.log ] && grep "kernel level\|module" $O/pqmf.log; [ -f $O/stft_loss.log ] && grep "sum over" $O/stft_loss.log
 [ -f $O/kernel_stats_step_b32_graph.md ] && { head -12 $O/kernel_stats_step_b32_graph.md; tail -1 $O/kernel_stats_step_b32_graph.md; }
 [ -f $O/pmc_traffic.log ] && cat $O/pmc_traffic.log | head -80

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p _var
-for p in mfma_clock tr_read fetch_calib mfma_valu_overlap unaligned_b128 lds_unaligned; do
-  [ -f $p.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _var/$p $p.hip
+for p in mfma_clock tr_read fetch_calib mfma_valu_overlap unaligned_b128 lds_unaligned f16x3 atomic_fanin; do
+  [ -f $p.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -o _var/$p $p.hip
 done
 ls -la _var | grep -v "\.so"

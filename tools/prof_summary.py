@@ -14,7 +14,7 @@ def main(path, out=None, steps=None):
     rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by {name_col} order by 3 desc").fetchall()
     total = sum(r[2] for r in rows)
     lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
-    for n, c, s, a, mn, mx in rows[:45]:
+    for n, c, s, a, mn, mx in rows[:90]:
         lines.append(f"| {short(n)} | {c} | {s/1e6:.3f} | {a/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {100*s/total:.1f} |")
     lines.append(f"\ntotal kernel time {total/1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches")
     txt = "\n".join(lines)

@@ -11,12 +11,13 @@ mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 for v in ${VARS:-0 1 2 3 4 5 6 7}; do
   (
-    for f in conv_x6_is1 conv_x6_is2 conv_x6_is4; do
-      /opt/rocm/bin/hipcc $FLAGS -DRH_X6_VAR=$v -x hip -c rave_amd/csrc/$f.hip -o $OUT/${f}_v$v.o &
+    # (the stride-1 shapes only: the layers tools/x6_variants_run.sh times)
+    for f in rave_amd/csrc/conv_x6_i1_*.hip; do
+      b=$(basename $f .hip)
+      /opt/rocm/bin/hipcc $FLAGS -DRH_X6_VAR=$v -x hip -c $f -o $OUT/${b}_v$v.o
     done
-    wait
-    others=$(ls $OBJ/*.o | grep -v "conv_x6_is[124]")
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/librave_hip_v$v.so $others $OUT/conv_x6_is1_v$v.o $OUT/conv_x6_is2_v$v.o $OUT/conv_x6_is4_v$v.o
+    others=$(ls $OBJ/*.o | grep -v "conv_x6_i1_")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/librave_hip_v$v.so $others $OUT/conv_x6_i1_*_v$v.o
     rm -f $OUT/*_v$v.o
   ) &
 done
