@@ -101,8 +101,11 @@ def load_lmdb_dataset(db_path: str, n_channels: Optional[int] = None, audio_key:
     if info.get("lazy"):
         raise RuntimeError("rave_amd.data.load_lmdb_dataset: lazy dataset (audio decoded on the fly by ffmpeg): no PCM in the store")
     ch = int(n_channels or info.get("channels", 1))
-    chunks = []
-    with LmdbReader(db_path) as db:
+    # two passes, one copy (a list of per-item copies + np.stack + pin_memory held the dataset three times): the first
+    # pass only counts the items and their lengths, the second writes each item straight into its row of ONE preallocated
+    # (pinned, when a GPU is present and the data stays on the host) int16 tensor
+    def items(db):
+        n = 0
         for k, v in db.items():
             buffers, _ = parse_audio_example(v)
             if audio_key not in buffers:
@@ -110,19 +113,27 @@ def load_lmdb_dataset(db_path: str, n_channels: Optional[int] = None, audio_key:
             raw = buffers[audio_key]["data"]
             if len(raw) % (2 * ch):
                 raise RuntimeError(f"load_lmdb_dataset: item {k!r} holds {len(raw)} bytes, not a whole number of {ch}-channel int16 frames")
-            chunks.append(np.frombuffer(raw, dtype=np.int16).reshape(ch, -1).copy())
-            if max_items is not None and len(chunks) >= max_items:
-                break
-    if not chunks:
-        raise RuntimeError(f"load_lmdb_dataset: no '{audio_key}' buffers found under {db_path}")
-    lengths = [c.shape[1] for c in chunks]
-    common = max(set(lengths), key=lengths.count)
-    keep = [c for c in chunks if c.shape[1] == common]
-    pcm = torch.from_numpy(np.stack(keep, 0))
+            yield raw
+            n += 1
+            if max_items is not None and n >= max_items:
+                return
+
+    with LmdbReader(db_path) as db:
+        lengths = [len(raw) // (2 * ch) for raw in items(db)]
+        if not lengths:
+            raise RuntimeError(f"load_lmdb_dataset: no '{audio_key}' buffers found under {db_path}")
+        common = max(set(lengths), key=lengths.count)
+        n_keep = lengths.count(common)
+        pcm = torch.empty(n_keep, ch, common, dtype=torch.int16, pin_memory=(device is None and torch.cuda.is_available()))
+        view = pcm.numpy()
+        row = 0
+        for raw in items(db):
+            if len(raw) // (2 * ch) == common:
+                view[row] = np.frombuffer(raw, dtype=np.int16).reshape(ch, -1)
+                row += 1
     if device is not None:
         pcm = pcm.to(device)
-    elif torch.cuda.is_available():
-        pcm = pcm.pin_memory()
+    keep, chunks = range(n_keep), lengths
     out = dict(sr=int(info.get("sr", 44100)), channels=ch, lazy=False, n_items=len(keep), length=common,
                dropped=len(chunks) - len(keep))
     return pcm, out

@@ -209,6 +209,8 @@ class LmdbReader:
 def _varint(buf, pos: int) -> Tuple[int, int]:
     out = shift = 0
     while True:
+        if pos >= len(buf):
+            raise LmdbFormatError("truncated protobuf varint")
         b = buf[pos]
         pos += 1
         out |= (b & 0x7F) << shift

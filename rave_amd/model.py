@@ -301,6 +301,10 @@ class RAVE(nn.Module):
                 multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
             for t_ in (x_multiband, y_multiband):
                 t_.record_stream(loss_side)
+            # the distances were allocated from the side stream's pool and are consumed on the compute stream (loss_combine)
+            for v_ in multiband_distance.values():
+                if torch.is_tensor(v_):
+                    v_.record_stream(torch.cuda.current_stream(batch.device))
         else:
             multiband_distance = self.multiband_audio_distance(x_multiband, y_multiband)
         for k, v in multiband_distance.items():
@@ -423,7 +427,9 @@ class RAVE(nn.Module):
         z = self.encoder.reparametrize(z, eps)[0]
         y = self.decode(z)
         distance = self.audio_distance(x, y)
-        self.logged["validation"] = sum(distance.values())
+        # a NEW dict (the current one may be the object a GraphedTrainingStep hands back at every replay: writing into it would
+        # leak a stale entry into all later training logs -- ADVICE r5), the value detached
+        self.logged = dict(self.logged, validation=sum(distance.values()).detach())
         self.release_weights()
         return torch.cat([x, y], -1), mean
 

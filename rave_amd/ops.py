@@ -540,9 +540,6 @@ class _OnSide:
         self.ctx.__exit__(*exc)
         for t in self.tensors:
             t.record_stream(self.side)
-        import os
-        if os.environ.get("RH_SIDE_HOLD", "1") != "0":      # (0: the unprotected form, for the test that shows the race)
-            _SIDE_HOLD.extend(self.hold)
         # The join is queued once per BACKWARD PASS (graph task).  A pass that raised after queueing never ran its callback
         # and left the pending state behind: a pending entry of ANOTHER pass is joined here and now, so that its
         # collected weight-norm launch still runs and a later pass queues its own join.
@@ -551,6 +548,9 @@ class _OnSide:
         if pend is not None and pend[2] != task:
             join_side_streams()
             pend = None
+        # (after the stale join, which clears _SIDE_HOLD: this node's holds must survive until ITS join -- ADVICE r5)
+        if os.environ.get("RH_SIDE_HOLD", "1") != "0":      # (0: the unprotected form, for the test that shows the race)
+            _SIDE_HOLD.extend(self.hold)
         if pend is None:
             _SIDE_PENDING[0] = (self.main, self.side, task)
             try:        # end of this backward pass: the compute stream waits for the branch
@@ -1159,6 +1159,9 @@ class _AdainTransferFn(torch.autograd.Function):
     def forward(ctx, x, mean_x, std_x, mean_y, std_y):
         x = _chk(x, "x")
         b, c, l = x.shape
+        for t in (mean_x, std_x, mean_y, std_y):     # the kernel walks b * c rows of each: refuse what it would read out of bounds
+            if t.dim() < 2 or b > t.shape[0] or t.shape[1] != c or t[:b].numel() != b * c:
+                raise ValueError(f"adain statistics {tuple(t.shape)} do not cover a batch of {b} x {c} channels")
         stats = [_chk(t[:b], "statistics") for t in (mean_x, std_x, mean_y, std_y)]
         y = torch.empty_like(x)
         L.check(L.lib.rh_adain_transfer_f32(L.ptr(x), b * c, l, *[L.ptr(t) for t in stats], L.ptr(y), L.stream()), "adain_transfer")

@@ -1796,3 +1796,40 @@ def test_pqmf_folded_form_is_gated_on_the_stored_bank(dev):
     assert torch.equal(y, R.pqmf_analysis(x, m.forward_conv.weight, m.forward_conv._pad))
     ref = O.pqmf_analysis(x.cpu(), m.forward_conv.weight.detach().cpu())
     assert rel_l2(y, ref) < TOL_OP
+
+
+@pytest.mark.gpu
+def test_f16_piece_kernels_keep_f32_accuracy_across_the_dynamic_range_of_a_batch(dev):
+    """Round 6: the x6 kernels scale an operand by ONE power of two per TENSOR (range slot) and represent every element as
+    two f16 pieces -- a fixed-point window of 2^-39 of the tensor maximum (csrc/common.hpp).  A quiet clip next to a loud one
+    therefore keeps f32-class accuracy down to ~2^-15 of the loudest sample of the batch.  Checked against an fp64 evaluation:
+    forward, data gradient and weight gradient of a k = 3 dilated conv whose batch items differ by 2^0 ... 2^-12 in level,
+    error measured PER CLIP relative to that clip's own output (the reference's f32 conv: ~3e-7 everywhere); and the range
+    slots a launch publishes cover its outputs."""
+    from rave_amd import _lib as Lb, ops as R
+    from rave_amd.ops import ConvGeom
+    if Lb.lib.rh_x6_uses_ranges() != 1:
+        pytest.skip("comparison build (three bf16 pieces): no scales")
+    gen = torch.Generator().manual_seed(11)
+    B, C, L = 8, 96, 2048
+    levels = torch.tensor([1.0, 2.0 ** -2, 2.0 ** -4, 2.0 ** -6, 2.0 ** -8, 2.0 ** -10, 2.0 ** -12, 1.0]).view(B, 1, 1)
+    x = (torch.randn(B, C, L, generator=gen) * levels)
+    w = torch.randn(C, C, 3, generator=gen) / (3 * C) ** 0.5
+    cot = torch.randn(B, C, L, generator=gen) * levels
+    g = ConvGeom(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2)
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = R.conv1d(xd, wd, geom=g)
+    slot = getattr(y, "_rh_range", None)
+    assert slot is not None and float(slot[0].view(torch.float32).max()) >= float(y.detach().abs().max())
+    gx, gw = torch.autograd.grad(y, (xd, wd), cot.to(dev))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv1d(F.leaky_relu(x64, 0.2), w64, padding=3, dilation=3)
+    gx64, gw64 = torch.autograd.grad(y64, (x64, w64), cot.double())
+    worst = 0.0
+    for b in range(B):
+        for got, ref in ((y.detach()[b], y64[b]), (gx[b], gx64[b])):
+            e = rel_l2(got.cpu().double(), ref.detach())
+            worst = max(worst, e)
+            assert e < 2e-6, (b, float(levels[b]), e)
+    assert rel_l2(gw.cpu().double(), gw64) < 2e-6
+    print(f"f16 pieces, clips at 2^0 ... 2^-12 of the loudest: worst per-clip rel-L2 vs fp64 {worst:.2e}")

@@ -50,8 +50,10 @@ if has count; then    # dispatches per REPLAYED step: two graph runs that differ
                       # warm-up, capture, set-up -- cancels in the difference)
   for n in 20 60; do
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/cnt$n -o p -- python $GRAFT_REPO_ROOT/bench.py --steps $n --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/$O/cnt$n.log 2>&1 < /dev/null)
-    f=$(find $O/cnt$n -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f > $O/cnt$n.md 2>&1; rm -rf $O/cnt$n
+    f=$(find $O/cnt$n -name "*.db" | head -1); [ -n "$f" ] && python tools/prof_summary.py $f > $O/cnt$n.md 2>&1
   done
+  python tools/prof_diff.py $(find $O/cnt20 -name "*.db" | head -1) $(find $O/cnt60 -name "*.db" | head -1) 40 $O/kernel_stats_per_replayed_step.md > /dev/null 2>&1
+  rm -rf $O/cnt20 $O/cnt60
   python - <<PY > $O/dispatches_per_step.txt
 import re
 def tot(p):
