@@ -628,7 +628,16 @@ __global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __rest
     const long r = (long)blockIdx.x - p.row_begin;
     const float* vr = p.v + r * p.cols;
     float s = 0.f, mx = 0.f, sm = 0.f;
-    for (long e = threadIdx.x; e < p.cols; e += 256) {
+    // (per-thread order of the sum of squares: element e, e + 256, ... as ever -- the norms keep their bits; the loads go four
+    // rounds at a time so that a row of a few KB is not one dependent load per 1 KB)
+    long e = threadIdx.x;
+    for (; e + 768 < p.cols; e += 1024) {
+        const float a0 = vr[e], a1 = vr[e + 256], a2 = vr[e + 512], a3 = vr[e + 768];
+        s += a0 * a0; s += a1 * a1; s += a2 * a2; s += a3 * a3;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a0), fabsf(a1))), fmaxf(fabsf(a2), fabsf(a3)));
+        sm += fabsf(a0); sm += fabsf(a1); sm += fabsf(a2); sm += fabsf(a3);
+    }
+    for (; e < p.cols; e += 256) {
         const float a = vr[e];
         s += a * a;
         mx = fmaxf(mx, fabsf(a));
