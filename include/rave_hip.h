@@ -128,9 +128,13 @@ int rh_conv1d_pack_wn_f32(const rh_conv1d_desc* d, const float* v, const float* 
 
 /* Batched form of rh_conv1d_pack_wn_f32 for a whole model: the caller fills one opaque item per
  * weight-normalised conv (host memory, rh_prep_item_bytes() each, pointers are DEVICE pointers to the
- * parameters and to persistent norms / scale / packed buffers), links them, copies the array to the
- * device once, and then refreshes every layer's packed weights with TWO launches per training step. */
+ * parameters and to persistent norms / scale / packed buffers; the array is rh_prep_array_bytes(n) long: the items and,
+ * behind them, two compact lookup tables rh_prep_link writes), links them, copies the array to the
+ * device once, and then refreshes every layer's packed weights with three launches (range clear, scales, pack) per training step. */
 int64_t rh_prep_item_bytes(void);
+int64_t rh_prep_array_bytes(int32_t n);
+/* (rh_prep_fill_item: `scale` must hold 3 * rows floats -- the scales, then the per-row max |w| and sum |w| the range
+ * records of the f16 kernels are reduced from.) */
 int rh_prep_fill_item(const rh_conv1d_desc* d, const float* v, const float* g, float* norms, float* scale,
                       float* wp_fwd, float* wp_bwd, void* item_host);
 int rh_prep_link(void* items_host, int32_t n, int64_t* total_rows, int64_t* total_blocks);

@@ -76,6 +76,7 @@ def _load() -> C.CDLL:
         "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
         "rh_conv1d_pack_wn_f32": ([D, P, P, P, P, P, P, P], C.c_int),
         "rh_prep_item_bytes": ([], I64),
+        "rh_prep_array_bytes": ([I32], I64),
         "rh_prep_fill_item": ([D, P, P, P, P, P, P, P], C.c_int),
         "rh_prep_link": ([P, I32, C.POINTER(I64), C.POINTER(I64)], C.c_int),
         "rh_prep_run_f32": ([P, I32, I64, I64, P], C.c_int),

@@ -604,21 +604,38 @@ struct PrepItem {
 
 namespace {
 
+// Which item does row / pack tile `key` belong to?  The prefix sums live a SECOND time in two compact tables behind the n items
+// (rh_prep_link: long row_begin[n], long blk_begin[n]): the binary search then walks ~0.5 KB that stays in the scalar cache,
+// instead of one ~3 KB PrepItem per probe -- six dependent cache misses at the head of every one of ~35 k tiny workgroups were
+// most of the two kernels' time (round 6).
 __device__ __forceinline__ int find_item(const PrepItem* items, int n, long key, bool rows) {
+    const long* tab = reinterpret_cast<const long*>(items + n) + (rows ? 0 : n);
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        const long b = rows ? items[mid].row_begin : items[mid].blk_begin;
-        if (b <= key) lo = mid; else hi = mid - 1;
+        if (tab[mid] <= key) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
 
-__global__ __launch_bounds__(256) void prep_clear_kernel(const PrepItem* __restrict__ items, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * n) return;
-    unsigned* r = (i & 1) ? items[i >> 1].bwd.range : items[i >> 1].fwd.range;
-    if (r) { r[0] = 0u; r[1] = 0u; r[2] = 0u; r[3] = 0u; }
+// Range record of every layer from the per-row maxima prep_scales_kernel left behind `scale` (scale[rows + r] = max |w| of row
+// r, scale[2 rows + r] = its sum |w|): one workgroup per item, plain stores into both packed copies' records.  (Round 6 first
+// had every row's workgroup atomicMax into the records: ~70 k same-line atomics made prep_scales_kernel 52 -> 120 us.)
+__global__ __launch_bounds__(256) void prep_range_kernel(const PrepItem* __restrict__ items, int n) {
+    __shared__ float red[8];
+    const PrepItem& p = items[blockIdx.x];
+    float mx = 0.f, l1 = 0.f;
+    for (long r = threadIdx.x; r < p.rows; r += 256) { mx = fmaxf(mx, p.scale[p.rows + r]); l1 = fmaxf(l1, p.scale[2 * p.rows + r]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_down(mx, o, 64)); l1 = fmaxf(l1, __shfl_down(l1, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; red[4 + (threadIdx.x >> 6)] = l1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned m = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        const unsigned l = __float_as_uint(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        for (unsigned* r : {p.fwd.range, p.bwd.range})
+            if (r) { r[0] = m; r[1] = l; r[2] = 0u; r[3] = 0u; }
+    }
 }
 
 __global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __restrict__ items, int n) {
@@ -656,11 +673,11 @@ __global__ __launch_bounds__(256) void prep_scales_kernel(const PrepItem* __rest
         const float sc = p.g[r] / norm;
         p.norms[r] = norm;
         p.scale[r] = sc;
-        // range record of the layer (pack_range_kernel's arithmetic): read by prep_pack_kernel and by the f16 conv kernels
+        // per-row range statistics (pack_range_kernel's arithmetic), reduced per layer by prep_range_kernel
         const float m = fabsf(sc) * fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         const float l1 = fabsf(sc) * ((red[8] + red[9]) + (red[10] + red[11]));
-        if (p.fwd.range) { atomicMax(p.fwd.range, __float_as_uint(m)); atomicMax(p.fwd.range + 1, __float_as_uint(l1)); }
-        if (p.bwd.range) { atomicMax(p.bwd.range, __float_as_uint(m)); atomicMax(p.bwd.range + 1, __float_as_uint(l1)); }
+        p.scale[p.rows + r] = m;
+        p.scale[2 * p.rows + r] = l1;
     }
 }
 
@@ -679,6 +696,8 @@ __global__ __launch_bounds__(256) void prep_pack_kernel(const PrepItem* __restri
 }  // namespace
 
 extern "C" int64_t rh_prep_item_bytes(void) { return (int64_t)sizeof(PrepItem); }
+// bytes of the whole item array for n items: the items + the two compact prefix tables rh_prep_link writes behind them
+extern "C" int64_t rh_prep_array_bytes(int32_t n) { return (int64_t)n * (int64_t)sizeof(PrepItem) + 2 * (int64_t)n * (int64_t)sizeof(long); }
 
 extern "C" int rh_prep_fill_item(const rh_conv1d_desc* d, const float* v, const float* g, float* norms, float* scale,
                                  float* wp_fwd, float* wp_bwd, void* item) {
@@ -704,6 +723,8 @@ extern "C" int rh_prep_link(void* items, int32_t n, int64_t* total_rows, int64_t
         rows += p[i].rows;
         for (const PackP* q : {&p[i].fwd, &p[i].bwd}) blks += pack_tiles(*q);
     }
+    long* tab = reinterpret_cast<long*>(p + n);           // (the caller allocated rh_prep_array_bytes(n))
+    for (int i = 0; i < n; ++i) { tab[i] = p[i].row_begin; tab[n + i] = p[i].blk_begin; }
     *total_rows = rows;
     *total_blocks = blks;
     return RH_OK;
@@ -713,12 +734,11 @@ extern "C" int rh_prep_run_f32(const void* items_dev, int32_t n, int64_t total_r
                                rh_stream_t stream) {
     RH_REQUIRE(items_dev && n > 0, RH_ERR_INVALID, "prep_run: bad arguments");
     if (total_rows > 0) {
-        hipLaunchKernelGGL(prep_clear_kernel, dim3((unsigned)rh_cdiv(2 * n, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const PrepItem*)items_dev, n);
-        if (int e = rh_check_launch("prep_clear")) return e;
         hipLaunchKernelGGL(prep_scales_kernel, dim3((unsigned)total_rows), dim3(256), 0, (hipStream_t)stream,
                            (const PrepItem*)items_dev, n);
         if (int e = rh_check_launch("prep_scales")) return e;
+        hipLaunchKernelGGL(prep_range_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const PrepItem*)items_dev, n);
+        if (int e = rh_check_launch("prep_range")) return e;
     }
     if (total_blocks > 0) {
         hipLaunchKernelGGL(prep_pack_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,

@@ -253,18 +253,32 @@ def _ws(nbytes: int, device) -> Optional[Tensor]:
 # computes the same scales as an eager one).
 _RANGES = L.lib.rh_x6_uses_ranges() == 1
 _RANGE_WORDS = L.lib.rh_x6_range_words()
-_RANGE_SLOTS = 512      # 4 KB each
-_RANGE_POOLS = {}        # device -> [pool, cursor, previous pool (kept alive: a side stream may still read it)]
+_RANGE_SLOTS = 2048     # 4 KB each: more than any step of the shipped configs uses (a pool that runs out mid-step is replaced)
+_RANGE_POOLS = {}        # device -> [pool, cursor, previous pool (kept alive: a side stream may still read it), stream of the reset]
 
 
-def range_reset(device=None) -> None:
+def range_reset(device=None, _exhausted: bool = False) -> None:
     """Start a fresh zeroed slot pool (call at the start of a step; mandatory inside a hipGraph capture)."""
     if not _RANGES:
         return
     for dev in ([device] if device is not None else list(_RANGE_POOLS)):
         st = _RANGE_POOLS.get(dev)
         prev = st[0] if st else None
-        _RANGE_POOLS[dev] = [torch.zeros(_RANGE_SLOTS * _RANGE_WORDS, device=dev, dtype=torch.int32), 0, prev]
+        cur = torch.cuda.current_stream(dev)
+        pool = torch.zeros(_RANGE_SLOTS * _RANGE_WORDS, device=dev, dtype=torch.int32)
+        if _exhausted:
+            # a pool that ran out in the middle of a step, possibly on the weight-gradient side stream: the other stream of the
+            # step must not publish into the new pool before its zero fill has run
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            d_ = dev if isinstance(dev, torch.device) else torch.device(dev)
+            for other in [st[3] if st else None, _SIDE.get(d_.index if d_.index is not None else torch.cuda.current_device())]:
+                if other is not None and other != cur:
+                    other.wait_event(ev)
+            main = st[3] if st else cur
+        else:
+            main = cur
+        _RANGE_POOLS[dev] = [pool, 0, prev, main]
 
 
 def _ranges_on() -> bool:
@@ -274,7 +288,7 @@ def _ranges_on() -> bool:
 def _new_range(device) -> Tensor:
     st = _RANGE_POOLS.get(device)
     if st is None or st[1] >= _RANGE_SLOTS:
-        range_reset(device)
+        range_reset(device, _exhausted=st is not None)
         st = _RANGE_POOLS[device]
     i = st[1]
     st[1] = i + 1

@@ -53,7 +53,7 @@ class WeightPrep:
         if self.n == 0:
             return
         isz = L.lib.rh_prep_item_bytes()
-        host = (C.c_uint8 * (isz * self.n))()
+        host = (C.c_uint8 * L.lib.rh_prep_array_bytes(self.n))()      # the items + the lookup tables rh_prep_link appends
         dev = self.mods[0].weight_v.device
         for i, m in enumerate(self.mods):
             v, g = m.weight_v, m.weight_g
@@ -63,7 +63,8 @@ class WeightPrep:
             d = _desc(_geom_of(m), 1, c_in, c_out, 1, 1, k)
             dref = C.byref(d)
             rows = v.shape[0]
-            ns = torch.empty(2, rows, device=dev, dtype=torch.float32)
+            # norms | scale | per-row max |w| | per-row sum |w| (the last two: range statistics rh_prep_run_f32 keeps behind scale)
+            ns = torch.empty(4, rows, device=dev, dtype=torch.float32)
             wp_f = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 0), device=dev, dtype=torch.float32)
             wp_b = torch.empty(L.lib.rh_conv1d_packed_floats(dref, 1), device=dev, dtype=torch.float32)
             item = C.cast(C.byref(host, i * isz), C.c_void_p)
