@@ -819,9 +819,7 @@ extern "C" int rh_conv1d_fwd_f32(const rh_conv1d_desc* d, const float* x, const 
     RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv1d_fwd: null pointer");
     RH_REQUIRE(d->act != RH_ACT_SNAKE || snake_alpha, RH_ERR_INVALID, "conv1d_fwd: snake needs alpha");
     if (rh_smallc_fwd_eligible(d, residual != nullptr)) {
-        if (int e = rh_smallc_fwd(d, x, wp_fwd, bias, y, (hipStream_t)stream)) return e;
-        p.out = y;
-        return rh_range_after(p, (hipStream_t)stream);
+        return rh_smallc_fwd(d, x, wp_fwd, bias, y, (hipStream_t)stream, p.out_range);     // (publishes max |y| itself)
     }
     p.in = x; p.wp = wp_fwd; p.out = y; p.bias = bias; p.add = residual; p.mul_src = nullptr;
     p.wq = reinterpret_cast<const unsigned*>(wp_fwd + p.x6_wofs);

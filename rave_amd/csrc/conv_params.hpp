@@ -188,7 +188,8 @@ bool rh_conv_x6_plan_query(ConvP p, int* out7);
 
 // Vector-ALU kernels for the 1- / 2-channel first layers of the discriminators (conv_smallc.hip)
 bool rh_smallc_fwd_eligible(const rh_conv1d_desc* d, bool has_residual);
-int rh_smallc_fwd(const rh_conv1d_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, hipStream_t stream);
+int rh_smallc_fwd(const rh_conv1d_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, hipStream_t stream,
+                  unsigned* out_range = nullptr);
 bool rh_smallc_dgrad_eligible(const rh_conv1d_desc* d, bool has_add);
 int rh_smallc_dgrad(const rh_conv1d_desc* d, const float* dy, const float* wp_bwd, const int* slot_of_tap, float* dx,
                     hipStream_t stream);

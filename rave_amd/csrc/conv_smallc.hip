@@ -30,6 +30,7 @@ struct SmallP {
     int nblk;              // position blocks per batch item
     int total_blocks;      // wgrad: B * nblk
     int slot[16];          // dgrad: packed slot of tap t
+    unsigned* out_range;   // forward: range slot that receives max |y| (consumers on the f16 kernels, common.hpp) or null
 };
 
 template <int K, int C>
@@ -45,24 +46,31 @@ __global__ __launch_bounds__(256) void smallc_fwd_kernel(const SmallP p) {
     __syncthreads();
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + tid;
-    if (n >= p.l_out) return;
-    float xv[KC];
+    float amax = 0.f;
+    if (n < p.l_out) {
+        float xv[KC];
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int t = 0; t < K; ++t) {
-            const int pos = n * p.s - p.pad + t;
-            xv[c * K + t] = (pos >= 0 && pos < p.l_in) ? p.x[((long)b * C + c) * p.l_in + pos] : 0.f;
-        }
-    float* __restrict__ dst = p.out + (long)b * p.M * p.l_out + n;
-    const bool leaky = p.out_act == RH_ACT_LEAKY;
+            for (int t = 0; t < K; ++t) {
+                const int pos = n * p.s - p.pad + t;
+                xv[c * K + t] = (pos >= 0 && pos < p.l_in) ? p.x[((long)b * C + c) * p.l_in + pos] : 0.f;
+            }
+        float* __restrict__ dst = p.out + (long)b * p.M * p.l_out + n;
+        const bool leaky = p.out_act == RH_ACT_LEAKY;
 #pragma unroll 2
-    for (int m = 0; m < p.M; ++m) {
-        float acc = p.bias ? p.bias[m] : 0.f;
+        for (int m = 0; m < p.M; ++m) {
+            float acc = p.bias ? p.bias[m] : 0.f;
 #pragma unroll
-        for (int i = 0; i < KC; ++i) acc = fmaf(wl[m * PITCH + i], xv[i], acc);
-        if (leaky) acc = acc > 0.f ? acc : acc * p.out_slope;
-        dst[(long)m * p.l_out] = acc;
+            for (int i = 0; i < KC; ++i) acc = fmaf(wl[m * PITCH + i], xv[i], acc);
+            if (leaky) acc = acc > 0.f ? acc : acc * p.out_slope;
+            dst[(long)m * p.l_out] = acc;
+            amax = fmaxf(amax, fabsf(acc));
+        }
+    }
+    if (p.out_range) {           // (uniform; every thread of the workgroup gets here)
+        __shared__ float red[4];
+        rh_range_publish(p.out_range, amax, blockIdx.x + blockIdx.y * 7u, red);
     }
 }
 
@@ -226,9 +234,10 @@ bool rh_smallc_fwd_eligible(const rh_conv1d_desc* d, bool has_residual) {
 }
 
 int rh_smallc_fwd(const rh_conv1d_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y,
-                  hipStream_t stream) {
+                  hipStream_t stream, unsigned* out_range) {
     SmallP p = base(d);
     p.x = x; p.w = wp_fwd; p.bias = bias; p.out = y;
+    p.out_range = out_range;
     by_shape(d, [&](auto kc, auto cc) {
         constexpr int K = decltype(kc)::value, C = decltype(cc)::value;
         const size_t lds = (size_t)p.M * ((K * C + 3) & ~3) * sizeof(float);

@@ -300,11 +300,41 @@ def _attach_range(t: Optional[Tensor], slot: Optional[Tensor]) -> None:
         t._rh_range = (slot, t._version)
 
 
-def _range_of(t: Tensor, s) -> Tensor:
-    """The range slot of ``t``: the one its producer left, else computed now (one pass over ``t`` on stream ``s``)."""
+_RANGE_MISS = None       # diagnostics (range_miss_log_begin): [(tag, shape)] of the tensors that needed an rh_amax_f32 pass
+
+
+def range_miss_log_begin() -> None:
+    global _RANGE_MISS
+    _RANGE_MISS = []
+
+
+def range_miss_log_end():
+    global _RANGE_MISS
+    out, _RANGE_MISS = _RANGE_MISS, None
+    return out
+
+
+def _valid_slot(t: Tensor):
     r = getattr(t, "_rh_range", None)
     if r is not None and r[1] == t._version and r[0].device == t.device:
         return r[0]
+    return None
+
+
+def _range_of(t: Tensor, s, tag: str = "") -> Tensor:
+    """The range slot of ``t``: the one its producer left -- also through a view that covers the whole producer tensor (same
+    elements, same maximum; views share the version counter) --, else computed now (one pass over ``t`` on stream ``s``)."""
+    slot = _valid_slot(t)
+    if slot is not None:
+        return slot
+    base = t._base
+    if base is not None and base.numel() == t.numel():
+        slot = _valid_slot(base)
+        if slot is not None:
+            t._rh_range = (slot, t._version)
+            return slot
+    if _RANGE_MISS is not None:
+        _RANGE_MISS.append((tag, tuple(t.shape)))
     slot = _new_range(t.device)
     L.check(L.lib.rh_amax_f32(L.ptr(t), t.numel(), L.ptr(slot), s), "amax")
     _attach_range(t, slot)
@@ -316,10 +346,13 @@ def _fwd(d, x, wp, bias, alpha, residual, y, s):
     ws = _ws(L.lib.rh_conv1d_fwd_workspace_bytes(C.byref(d)), y.device)
     rin = rout = None
     if _ranges_on():
-        rin, rout = _range_of(x, s), _new_range(y.device)
+        # the input's slot only where the f16 kernels will read it (family 1); the output's always (its consumers may)
+        if L.lib.rh_conv1d_kernel_family(C.byref(d), 0, int(bias is not None), int(residual is not None)) == 1:
+            rin = _range_of(x, s, "fwd x")
+        rout = _new_range(y.device)
 
     def run(out, ranges=True):
-        if ranges and rin is not None:
+        if ranges and rout is not None:
             L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(rout), None)
         return L.lib.rh_conv1d_fwd_f32(C.byref(d), L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(alpha), L.ptr(residual), L.ptr(out),
                                        L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s)
@@ -335,7 +368,7 @@ def _unit_fwd(d3, d1, x, wp3, wp1, h, y, s):
     """Fused Residual(DilatedUnit) forward (rh_residual_unit_fwd_f32); ``h`` None = inference (never written)."""
     rin = ry = rh = None
     if _RANGES:
-        rin, ry = _range_of(x, s), _new_range(x.device)
+        rin, ry = _range_of(x, s, "unit x"), _new_range(x.device)
         rh = _new_range(x.device) if h is not None else None
 
     def run(o_y, o_h):
@@ -377,10 +410,12 @@ def _dgrad(d, dy, wp, x, alpha, add, dx, s):
     ws = _ws(L.lib.rh_conv1d_bwd_data_workspace_bytes(C.byref(d)), dx.device)
     rin = rout = None
     if _ranges_on():
-        rin, rout = _range_of(dy, s), _new_range(dx.device)
+        if L.lib.rh_conv1d_kernel_family(C.byref(d), 1, 0, int(add is not None)) == 1:
+            rin = _range_of(dy, s, "dgrad dy")
+        rout = _new_range(dx.device)
 
     def run(out, ranges=True):
-        if ranges and rin is not None:
+        if ranges and rout is not None:
             L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(rout), None)
         return L.lib.rh_conv1d_bwd_data_f32(C.byref(d), L.ptr(dy), L.ptr(wp), L.ptr(x), L.ptr(alpha), L.ptr(add), L.ptr(out),
                                             L.ptr(ws), ws.numel() * 4 if ws is not None else 0, s)
@@ -574,15 +609,15 @@ class _OnSide:
         return False
 
 
-def _arm_wgrad_ranges(dy, x, s) -> None:
+def _arm_wgrad_ranges(dy, x, s, d=None) -> None:
     """Range slots of both operands for the next weight-gradient call (the f16 weight-gradient kernel converts both)."""
-    if _RANGES and os.environ.get("RH_WGRAD_X6", "1") != "0":
-        L.lib.rh_x6_set_ranges(L.ptr(_range_of(dy, s)), L.ptr(_range_of(x, s)), None, None)
+    if _RANGES and os.environ.get("RH_WGRAD_X6", "1") != "0" and (d is None or L.lib.rh_conv1d_bwd_weight_kernel_family(C.byref(d)) == 1):
+        L.lib.rh_x6_set_ranges(L.ptr(_range_of(dy, s, "wgrad dy")), L.ptr(_range_of(x, s, "wgrad x")), None, None)
 
 
 def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s):
     def run(o_dw, o_db):
-        _arm_wgrad_ranges(dy, x, s)
+        _arm_wgrad_ranges(dy, x, s, d)
         return L.lib.rh_conv1d_bwd_weight_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(o_dw), L.ptr(o_db), L.ptr(ws),
                                               nbytes, s)
 
@@ -697,7 +732,7 @@ def _wgrad_wn(d, dy, x, alpha, dw, db, v, g, norms, ws, nbytes, s, slot_v=None, 
         if len(_WN_PENDING) >= _WN_BATCH_MAX:      # (we are on the side stream here: the batch runs beside the data-gradient chain)
             _flush_wn_pending(s)
         return dv, dg
-    _arm_wgrad_ranges(dy, x, s)
+    _arm_wgrad_ranges(dy, x, s, d)
     L.check(L.lib.rh_conv1d_bwd_weight_wn_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(v), L.ptr(g), L.ptr(norms),
                                               L.ptr(dw), L.ptr(dv), L.ptr(dg), L.ptr(db), L.ptr(ws), nbytes, s),
             "conv1d_bwd_weight_wn")
