@@ -35,7 +35,9 @@ struct ConvP {
     int stage_floats;                          // floats per pipeline stage (weights + input tile)
     int ksplit;                                // K (channel-chunk) slices; > 1 -> raw partial sums go to `part`
     int chunks_per_split;
-    float* part;                               // [ksplit][B][M][out_row] scratch (caller workspace)
+    float* part;                               // [ksplit][B][M][out_row] scratch (caller workspace); x6 path: [ksplit][tile]
+                                               // register dumps of whole tiles (conv_x6_kernel.inc: x6_combine)
+    unsigned* tickets;                         // x6 path, ksplit > 1: one arrival counter per output tile, zero between launches
     long part_stride;                          // B*M*out_row
     unsigned in_bytes, w_bytes;                // buffer sizes for the bounds-checked DMA descriptors
     // --- x6 path (conv_x6.hip) only ---

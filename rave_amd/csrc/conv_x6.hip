@@ -1,9 +1,11 @@
 // Host side of the bf16x6 convolution path (kernels: conv_x6_kernel.inc): tile / split-K plan and launch.
+#include <atomic>
 #include <cstdlib>
 #include "conv_params.hpp"
 #include "conv2d_x6.hpp"
 
 // one translation unit per (input stride, tile shape): conv_x6_i<IS>_<TM><TN><WM>.hip
+int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream);
 bool rh_x6_launch_i1_121(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
 bool rh_x6_launch_i1_221(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
 bool rh_x6_launch_i1_321(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
@@ -34,7 +36,6 @@ bool rh_x6_launch_i4_211(const ConvP& q, int epi, dim3 grid, size_t lds, hipStre
 bool rh_x6_launch_i4_311(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
 bool rh_x6_launch_i4_212(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
 bool rh_x6_launch_i4_312(const ConvP& q, int epi, dim3 grid, size_t lds, hipStream_t stream);
-int rh_splitk_finalize_launch(ConvP& p, hipStream_t stream);
 
 namespace {
 
@@ -55,6 +56,38 @@ X6Launch x6_launcher(int is, int tm, int tn, int wm) {
 #undef RH_X6_S
     return nullptr;
 }
+// Arrival counters of the K-split launches (x6_combine): one word per output tile, zero whenever no launch that uses it is in
+// flight (the last arriver of a tile resets it).  A launch takes the next segment of ONE pool allocated (and zeroed) on first use
+// -- planning calls come first, so never under stream capture -- : launches that may overlap (two streams, graph branches) get
+// different segments, and a segment comes round again only after kTicketPool / tiles (thousands of) later launches.  The address
+// is baked into a captured graph node; replays of a node serialize.
+constexpr unsigned kTicketPool = 1u << 20;
+unsigned* ticket_pool() {
+    static unsigned* pool = [] {
+        unsigned* q = nullptr;
+        if (hipMalloc(&q, kTicketPool * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
+        if (hipMemset(q, 0, kTicketPool * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
+        return q;
+    }();
+    return pool;
+}
+unsigned* ticket_segment(unsigned n) {
+    static std::atomic<unsigned> next{0};
+    unsigned* pool = ticket_pool();
+    if (!pool || n > kTicketPool) return nullptr;
+    for (;;) {
+        unsigned at = next.load(std::memory_order_relaxed);
+        const unsigned start = at + n > kTicketPool ? 0u : at;
+        if (next.compare_exchange_weak(at, start + n, std::memory_order_relaxed)) return pool + start;
+    }
+}
+
+// K splits up to this many slices are combined inside the launch; finer ones by the finalize launch (RH_X6_COMBINE, read per call)
+int combine_max() {
+    const char* e = getenv("RH_X6_COMBINE");
+    return e ? atoi(e) : 8;
+}
+
 int epi_mode(const ConvP& p) { return (p.bias ? 1 : 0) | (p.mul_src ? 2 : 0) | (p.add ? 4 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0); }
 
 bool x6_enabled() {
@@ -174,7 +207,14 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     pl->chunks_per_split = rh_cdiv(total_chunks, z);
     pl->ksplit = rh_cdiv(total_chunks, pl->chunks_per_split);
     p.part_stride = (long)p.B * p.Mr * p.out_row;
-    pl->part_bytes = pl->ksplit > 1 ? (int64_t)pl->ksplit * p.part_stride * (int64_t)sizeof(float) : 0;
+    // scratch of a split launch: whole tiles as they lie in the registers, [slice][tile] (x6_combine)
+    // (or, for the finalize launch, in the output's layout: the larger of the two)
+    pl->part_bytes = 0;
+    if (pl->ksplit > 1) {
+        const int64_t tiled = (int64_t)pl->ksplit * blocks * (32 * pl->tm * pl->wm) * (32 * pl->tn * pl->wn) * (int64_t)sizeof(float);
+        const int64_t flat = (int64_t)pl->ksplit * p.part_stride * (int64_t)sizeof(float);
+        pl->part_bytes = tiled > flat ? tiled : flat;
+    }
     const unsigned long long in_b = 4ull * p.B * p.C * (unsigned long long)p.in_row;
     const unsigned long long row_span = (unsigned long long)p.Mr * (unsigned long long)p.out_row;
     const unsigned long long out_b = 4ull * (unsigned long long)p.part_stride;     // the epilogue's buffer descriptors
@@ -227,6 +267,7 @@ int64_t rh_conv_x6_workspace(ConvP p) {
     static const unsigned any_range[kRangeSlotWords] = {};
     if (!p.in_range) p.in_range = any_range;           // planning only: the answer does not depend on the slot
     if (!plan_x6(p, &pl)) return -1;
+    if (pl.part_bytes > 0) (void)ticket_pool();        // (allocated outside any stream capture: the planning call comes first)
     return pl.part_bytes;
 }
 
@@ -250,24 +291,30 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
     ConvP q = p;
     X6Plan pl{};
     if (!plan_x6(q, &pl)) return RH_OK;
-    if (pl.part_bytes > 0 && (!ws || ws_bytes < pl.part_bytes)) {     // no scratch offered: run unsplit
+    if (pl.part_bytes > 0 && (!ws || ws_bytes < pl.part_bytes || ((uintptr_t)ws & 15) || pl.part_bytes >= 0x7fffffffll)) {     // no (usable) scratch offered: run unsplit
         pl.ksplit = 1;
         pl.chunks_per_split = (q.C * q.is) >> 4;
     }
     q.in_bytes = (unsigned)(4ull * q.B * q.C * (unsigned long long)q.in_row);
     q.w_range = q.wq + q.wq_bytes / 4;                 // the range record behind the fragments (conv_host.hip: fill_pack)
+    q.tickets = nullptr;
+    if (pl.ksplit > 1 && pl.ksplit <= combine_max()) {
+        q.tickets = ticket_segment((unsigned)(pl.col_tiles * pl.row_tiles * q.nphase));
+        RH_REQUIRE(q.tickets, RH_ERR_INVALID, "%s: no arrival counters for a K-split launch (hipMalloc failed, or first use under stream capture)", what);
+    }
     q.part = (float*)ws;
     q.ksplit = pl.ksplit;
     q.chunks_per_split = pl.chunks_per_split;
     dim3 grid(pl.col_tiles, pl.row_tiles, q.nphase * q.ksplit);
-    // the epilogue is a template parameter of the kernel: K-slice launches store raw partial sums (mode 0)
-    const int epi = (q.ksplit > 1 ? 0 : epi_mode(q)) | (q.vs == 2 ? 16 : (q.vs == 4 ? 32 : 0));
+    // the epilogue is a template parameter of the kernel; a K-split launch combines its slices itself (x6_combine) and the last
+    // arriver of a tile runs the same epilogue
+    const int epi = (q.ksplit > 1 && !q.tickets ? 0 : epi_mode(q)) | (q.vs == 2 ? 16 : (q.vs == 4 ? 32 : 0));
     const X6Launch go = x6_launcher(q.is, pl.tm, pl.tn, pl.wm);
     RH_REQUIRE(go && go(q, epi, grid, pl.lds, stream), RH_ERR_UNSUPPORTED, "%s: no conv_x6_kernel instance for stride %d tile %d%d%d epilogue %d",
                what, q.is, pl.tm, pl.tn, pl.wm, epi);
     if (int e = rh_check_launch(what)) return e;
     *used = true;
-    if (q.ksplit > 1) {            // the partial sums are laid out like the output: finalize with the caller's (real-row) view
+    if (q.ksplit > 1 && !q.tickets) {   // the partial sums are laid out like the output: finalize with the caller's (real-row) view
         ConvP f = p;
         f.part = q.part; f.ksplit = q.ksplit; f.part_stride = q.part_stride;
         f.out_range = q.out_range;                     // the finalize pass sees the final values: it publishes their max

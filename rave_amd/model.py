@@ -564,6 +564,15 @@ class GraphedTrainingStep:
             g = torch.cuda.CUDAGraph()
             import os
             kw = {}
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # The process group's watchdog thread wakes every 100 ms and queries the end events of the collectives it
+                # still lists -- those of the eager warm-up steps, long complete.  This HIP runtime refuses hipEventQuery on an
+                # event whose STREAM has meanwhile joined a capture (hipErrorCapturedEvent, although the event was recorded
+                # before), which the watchdog turns into an abort of the process: about one data-parallel capture in eight
+                # (profiles/round6_rccl_watchdog_abort.txt).  Let it retire the finished collectives before the recording starts.
+                import time
+                torch.cuda.synchronize()
+                time.sleep(0.5)
             if os.environ.get("RH_GRAPH_PRIORITY", "0") == "1":
                 # experiment: record the step on a HIGH-priority stream, so that the data-gradient chain (the critical path)
                 # wins the arbitration against the weight-gradient branch, which forks onto a default-priority stream
@@ -574,10 +583,35 @@ class GraphedTrainingStep:
                 # the watchdog turns into an abort of the process (ProcessGroupNCCL.cpp: Watchdog::run) -- intermittently, about
                 # one data-parallel capture in four on these boxes (round 5).  "thread_local" restricts the check to this thread.
                 kw["capture_error_mode"] = "thread_local"
-            with torch.cuda.graph(g, **kw):
-                if self.before_step is not None:
-                    self.before_step()
-                logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True, **self.sync_kw)
+            # A step that cannot be recorded (e.g. a collective of a backend without capture support) must leave the process fit for
+            # the caller's eager fallback: (1) the streams the refused step forked are joined back INSIDE the recording -- ending a
+            # capture with unjoined work fails and, on this runtime, leaves every stream of it in capture mode for good
+            # (tools/debug/gloo_capture_recover.py); (2) the refused call's error code is read away from the runtime's per-thread
+            # "last error", where the next checked call of this thread would trip over it.
+            err = None
+            try:
+                with torch.cuda.graph(g, **kw):
+                    try:
+                        if self.before_step is not None:
+                            self.before_step()
+                        logged = m.training_step(self.x, batch_idx, eps=self.eps, capture_safe=True, **self.sync_kw)
+                    except Exception as e:        # noqa: BLE001 -- handed on below, after the recording has been closed
+                        err = e
+                        from . import ops as _ops
+                        _ops.abandon_side_streams(rejoin=True)
+            except Exception as e:                # noqa: BLE001 -- the recording could not be closed either
+                err = err or e
+            if err is not None:
+                from . import ops as _ops
+                _ops.abandon_side_streams()
+                for _ in range(3):
+                    try:
+                        torch.cuda.synchronize()
+                        torch.zeros(1, device=self.x.device)
+                        break
+                    except Exception:             # noqa: BLE001 -- the stale error itself
+                        continue
+                raise err
             # the capture itself does not execute anything: parameters are still the restored ones
             self.graphs[key] = (g, logged)
         g, logged = self.graphs[key]

@@ -520,6 +520,22 @@ def join_side_streams() -> None:
         _SIDE_HOLD.clear()
 
 
+def abandon_side_streams(rejoin: bool = False) -> None:
+    """Forget the side-stream bookkeeping of a pass that will never be joined (a step whose graph capture was refused midway):
+    no kernel is launched -- the work recorded so far dies with the capture.  rejoin: the calling stream waits for the side
+    streams first, so that a stream capture that forked onto them can be ended."""
+    if rejoin:
+        cur = torch.cuda.current_stream()
+        for st in _SIDE.values():
+            try:
+                cur.wait_stream(st)
+            except Exception:             # noqa: BLE001 -- a side stream that never joined the capture
+                pass
+    _SIDE_PENDING[0] = None
+    _SIDE_HOLD.clear()
+    _WN_PENDING.clear()
+
+
 def _note_use(ctx, *params) -> None:
     """Forward side of the "exactly one pending use" rule of the side stream: a parameter that enters two nodes of one
     graph gets its two gradients ADDED by autograd on the compute stream -- which must not happen to a tensor the side

@@ -704,6 +704,56 @@ def test_weight_gradient_with_the_input_staged_once_per_position_is_bit_identica
     assert rel_l2(dw1, dwf) < 2e-6 and rel_l2(db1, dbf) < 2e-6
 
 
+COMBINE_CASES = [
+    # (name, batch, c_in, c_out, length, kernel, geometry kwargs, transposed) -- layers whose output tiles cannot fill the chip:
+    # conv_x6.hip cuts K into slices (plan query: ksplit > 1)
+    ("unit_k3_c768", 32, 768, 768, 64, 3, dict(dilation=1, pad_left=1, pad_right=1, act=1, slope=0.2), False),
+    ("unit_k1_c768", 32, 768, 768, 64, 1, dict(act=1, slope=0.2), False),
+    ("unit_k3_c384", 32, 384, 384, 256, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2), False),
+    ("down_768_1536_k4s2", 32, 768, 1536, 64, 4, dict(stride=2, pad_left=1, pad_right=1, act=1, slope=0.2), False),
+    ("up_1536_768_k4s2", 32, 1536, 768, 32, 4, dict(stride=2, pad_left=1, pad_right=1, transposed=True, act=1, slope=0.2), True),
+    ("head_1536_256_k3", 32, 1536, 256, 32, 3, dict(pad_left=1, pad_right=1, act=1, slope=0.2), False),
+    ("ragged_c384_b5_l37", 5, 384, 416, 37, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2), False),
+]
+
+
+@pytest.mark.parametrize("case", COMBINE_CASES, ids=[c[0] for c in COMBINE_CASES])
+def test_k_split_combined_inside_the_launch_equals_the_finalize_launch(dev, case):
+    """conv_x6_kernel's K split (round 6): the slices' accumulators are dumped as they lie in the registers, the workgroup that
+    draws the last ticket of a tile adds them up IN SLICE ORDER and runs the epilogue (conv_x6_kernel.inc: x6_combine;
+    RH_X6_COMBINE = largest slice count handled that way) -- against rounds 2-5's second launch (splitk_finalize*_kernel,
+    RH_X6_COMBINE=0): forward output and data gradient must be the SAME BITS (same sums in the same order; the power-of-two
+    output scale commutes with them), three times in a row (the tickets are back at zero after every launch), and agree with the
+    unsplit f32-input kernels to 2e-6."""
+    from rave_amd import ops as R
+    from rave_amd.ops import ConvGeom
+    _, batch, c_in, c_out, length, k, kw, transposed = case
+    gen = torch.Generator().manual_seed(41)
+    geom = ConvGeom(**kw)
+    x0 = torch.randn(batch, c_in, length, generator=gen).to(dev)
+    w0 = (torch.randn(*((c_in, c_out, k) if transposed else (c_out, c_in, k)), generator=gen) * 0.05).to(dev)
+    b0 = torch.randn(c_out, generator=gen).to(dev)
+
+    def run(**env):
+        with _Env(RH_BWD_SIDE_STREAM=0, **env):
+            x = x0.clone().requires_grad_(True)
+            w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = R.conv1d(x, w, b, geom=geom)
+            cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(42)).to(dev)
+            y.backward(cot)
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone()
+
+    y_fin, dx_fin = run(RH_X6_COMBINE=0)
+    for _ in range(3):
+        y_c, dx_c = run(RH_X6_COMBINE=16)
+        assert torch.isfinite(y_c).all() and torch.isfinite(dx_c).all()
+        assert torch.equal(y_c, y_fin), rel_l2(y_c, y_fin)
+        assert torch.equal(dx_c, dx_fin), rel_l2(dx_c, dx_fin)
+    y_f, dx_f = run(RH_CONV_X6=0)
+    assert rel_l2(y_c, y_f) < 2e-6 and rel_l2(dx_c, dx_f) < 2e-6
+
+
 WN_TAIL_CASES = [
     # (name, batch, c_in, c_out, length, kernel, geometry kwargs, transposed)
     ("unit_k3_c96", 8, 96, 96, 4096, 3, dict(dilation=3, pad_left=3, pad_right=3, act=1, slope=0.2), False),
