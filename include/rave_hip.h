@@ -179,7 +179,8 @@ int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1,
  * serialise; the rest stays zero), each the bit pattern of a non-negative float -- max |x| is the largest word (any
  * upper bound within a factor of ~2^10 of it keeps f32 accuracy; a too SMALL value overflows f16: the slot must cover the
  * tensor).  rh_x6_set_ranges arms the slots of the NEXT rh_conv1d_fwd_f32 / rh_conv1d_bwd_data_f32 / rh_residual_unit_fwd_f32
- * / rh_conv1d_bwd_weight[_wn]_f32 call of this thread (consumed by that call, like rh_set_kernel_events):
+ * / rh_conv1d_bwd_weight[_wn]_f32 / rh_conv2d_fwd_f32 / rh_conv2d_bwd_data_f32 / rh_conv2d_bwd_weight_f32 / rh_act_bwd_bias_f32
+ * (out = the slot of g) call of this thread (consumed by that call, like rh_set_kernel_events):
  *     in_a   weight gradient only: the slot of dy          in_b   the slot of the input activation (x; dy for bwd_data)
  *     out    where the call leaves max |output| (forward: y, bwd_data: dx; atomicMax, the caller zeroes it first) or NULL
  *     out2   rh_residual_unit_fwd_f32: the slot of the intermediate h, or NULL
@@ -287,7 +288,8 @@ int rh_snake_bwd_f32(const float* dy, const float* x, const float* alpha, int32_
 int rh_act_bwd_f32(const float* dy, const float* y, int32_t act, float slope, int64_t n, float* g, rh_stream_t stream);
 /* One pass for the backward prologue of a conv with a LeakyReLU on its OUTPUT (rave/discriminator.py:50,
  * rave/descript_discriminator.py:27): g = dy * act'(y) and dbias[m] = sum over (batch, plane) of g, on (B, M, plane)
- * tensors; ordered partial sums (deterministic).  workspace: rh_act_bwd_bias_workspace_bytes(M) bytes. */
+ * tensors; ordered partial sums (deterministic).  workspace: rh_act_bwd_bias_workspace_bytes(M) bytes.  With an output range
+ * slot armed (rh_x6_set_ranges) the pass also leaves max |g| there. */
 int64_t rh_act_bwd_bias_workspace_bytes(int32_t M);
 int rh_act_bwd_bias_f32(const float* dy, const float* y, int32_t act, float slope, int32_t B, int32_t M, int64_t plane, float* g,
                         float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream);

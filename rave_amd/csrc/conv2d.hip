@@ -19,7 +19,7 @@
 // wgrad2d_x6.hip: weight gradient on the bf16 matrix cores (<= 32 output channels, stride 1 along W)
 int64_t rh_wgrad2d_x6_workspace(const rh_conv2d_desc* d);
 int rh_wgrad2d_x6_launch(const rh_conv2d_desc* d, const float* dy, const float* x, float* dw, void* ws, int64_t ws_bytes,
-                         hipStream_t stream, bool* used);
+                         hipStream_t stream, bool* used, const unsigned* dy_range, const unsigned* x_range);
 // conv2d_smallm.hip: vector-ALU kernels for convolutions with <= 4 output rows (first-layer data gradient, scoring conv)
 bool rh_conv2d_smallm_eligible(const rh_conv2d_desc* d, int which);
 int rh_conv2d_smallm_launch(const rh_conv2d_desc* d, int which, const float* in, const float* wp, const float* bias, float* out,
@@ -1147,11 +1147,11 @@ int fill_pack2(const rh_conv2d_desc* d, int which, const float* w, float* wp, Pa
     if (units > 0 && units * 4 < 0x7fffffffl) {
         p->wq = reinterpret_cast<unsigned*>(wp + p->total);
         p->x6_mode = 1;
-        p->bf16x3 = 1;             // this operand keeps three bf16 pieces in every build (conv_params.hpp)
+        p->range = p->wq + units * 4;          // {max |w|, max row sum |w|, 0, 0} behind the fragments (conv_host.hip)
         for (int ph = 0; ph < t.nphase; ++ph)
             for (int tl = 0; tl < t.ntaps[ph]; ++tl) {
-                p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 6 * p->Mp);
-                p->q2n[t.tap0[ph] + tl] = t.ntaps[ph] * 6 * p->Mp;
+                p->q2a[t.tap0[ph] + tl] = (int)(ph_ofs[ph] + (long)tl * 2 * kX6P * p->Mp);
+                p->q2n[t.tap0[ph] + tl] = t.ntaps[ph] * 2 * kX6P * p->Mp;
             }
     }
     return RH_OK;
@@ -1185,7 +1185,7 @@ extern "C" int64_t rh_conv2d_packed_floats(const rh_conv2d_desc* d, int which) {
     // + the bf16x6 fragments of the same weights (6 bytes per weight: conv2d_x6.hip), for channel counts in blocks of 16
     const int T = d->kh * d->kw;
     const long units = rh_conv2d_x6_units((int)C, (int)M, 1, &T, nullptr);
-    return base + ((units > 0 && units * 4 < 0x7fffffffl) ? units * 4 : 0);
+    return base + ((units > 0 && units * 4 < 0x7fffffffl) ? units * 4 + 4 : 0);      // (+ the range record)
 }
 
 // Diagnostics (tests): which kernel family a forward (which = 0) / data-gradient (1) launch of this geometry takes and, for
@@ -1243,14 +1243,22 @@ extern "C" int rh_conv2d_pack_f32(const rh_conv2d_desc* d, const float* w, float
     PackP a, b;
     if (int e = fill_pack2(d, 0, w, wp_fwd, &a)) return e;
     if (int e = fill_pack2(d, 1, w, wp_bwd, &b)) return e;
-    return rh_pack_launch(a, b, (hipStream_t)stream, "conv2d_pack");
+    // (rows = output channels = dim 0 of w, columns = c_in * kh * kw: the range records of both copies, then the pack)
+    return rh_pack_launch(a, b, (hipStream_t)stream, "conv2d_pack", w, d->c_out, (long)d->c_in * d->kh * d->kw);
 }
 
 extern "C" int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const float* wp_fwd, const float* bias,
                                  float* y, rh_stream_t stream) {
+    const unsigned* in_range = nullptr;
+    unsigned* out_range = nullptr;
+    rh_take_ranges(nullptr, &in_range, &out_range, nullptr);       // consumed by this call whatever happens below
     if (int e = validate2(d)) return e;
     if (d->batch == 0) return RH_OK;
     RH_REQUIRE(x && wp_fwd && y, RH_ERR_INVALID, "conv2d_fwd: null pointer");
+    // kernels other than conv2d_x6_kernel do not publish the output's range: a requested slot is filled by a pass over y
+    auto range_after = [&](int e) {
+        return (e || !out_range) ? e : rh_amax_f32(y, (int64_t)d->batch * d->c_out * d->h_out * d->w_out, out_range, stream);
+    };
     Plan2 t;
     build_plan2(d, 0, &t);
     Conv2P p{};
@@ -1262,8 +1270,8 @@ extern "C" int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const 
     p.is_h = d->sh; p.is_w = d->sw; p.os_h = 1; p.os_w = 1;
     p.mul_act = RH_ACT_NONE; p.mul_slope = 0.f;
     p.epi_act = d->act; p.epi_slope = d->act_slope;
-    if (rh_conv2d_smallm_eligible(d, 0)) return rh_conv2d_smallm_launch(d, 0, x, wp_fwd, bias, y, (hipStream_t)stream);
-    if (rh_conv2d_smallc_fwd_eligible(d)) return rh_conv2d_smallc_fwd_launch(d, x, wp_fwd, bias, y, (hipStream_t)stream);
+    if (rh_conv2d_smallm_eligible(d, 0)) return range_after(rh_conv2d_smallm_launch(d, 0, x, wp_fwd, bias, y, (hipStream_t)stream));
+    if (rh_conv2d_smallc_fwd_eligible(d)) return range_after(rh_conv2d_smallc_fwd_launch(d, x, wp_fwd, bias, y, (hipStream_t)stream));
     {   // exact f32 on the bf16 matrix cores where the geometry allows (C in blocks of 16): conv2d_x6.hip
         C2X q;
         fill_c2x(t, d->c_in, d->c_out, wp_fwd, &q);
@@ -1274,19 +1282,26 @@ extern "C" int rh_conv2d_fwd_f32(const rh_conv2d_desc* d, const float* x, const 
             q.rows = d->h_out; q.qcols = d->w_out;
             q.is_h = d->sh; q.is_w = d->sw; q.os_h = 1; q.os_w = 1;
             q.out_act = d->act; q.out_slope = d->act_slope;
+            q.in_range = in_range; q.out_range = out_range;
             bool used = false;
             if (int e = rh_conv2d_x6_launch(q, (hipStream_t)stream, "conv2d_fwd_x6", &used)) return e;
             if (used) return RH_OK;
         }
     }
-    return launch_conv2(p, t, (hipStream_t)stream, "conv2d_fwd");
+    return range_after(launch_conv2(p, t, (hipStream_t)stream, "conv2d_fwd"));
 }
 
 extern "C" int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* wp_bwd,
                                       float* dx, rh_stream_t stream) {
+    const unsigned* in_range = nullptr;
+    unsigned* out_range = nullptr;
+    rh_take_ranges(nullptr, &in_range, &out_range, nullptr);
     if (int e = validate2(d)) return e;
     if (d->batch == 0) return RH_OK;
     RH_REQUIRE(dy && wp_bwd && dx, RH_ERR_INVALID, "conv2d_bwd_data: null pointer");
+    auto range_after = [&](int e) {
+        return (e || !out_range) ? e : rh_amax_f32(dx, (int64_t)d->batch * d->c_in * d->h_in * d->w_in, out_range, stream);
+    };
     RH_REQUIRE(d->act == RH_ACT_NONE || y, RH_ERR_INVALID, "conv2d_bwd_data: the output activation needs y");
     Plan2 t;
     build_plan2(d, 1, &t);
@@ -1300,7 +1315,7 @@ extern "C" int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, 
     p.is_h = 1; p.is_w = 1; p.os_h = d->sh; p.os_w = d->sw;
     p.mul_act = d->act; p.mul_slope = d->act_slope;
     p.epi_act = RH_ACT_NONE; p.epi_slope = 0.f;
-    if (rh_conv2d_smallm_eligible(d, 1)) return rh_conv2d_smallm_launch(d, 1, dy, wp_bwd, nullptr, dx, (hipStream_t)stream);
+    if (rh_conv2d_smallm_eligible(d, 1)) return range_after(rh_conv2d_smallm_launch(d, 1, dy, wp_bwd, nullptr, dx, (hipStream_t)stream));
     if (d->act == RH_ACT_NONE) {   // (the caller has folded act'(y) into dy: rave_amd.ops._Conv2dFn.backward)
         C2X q;
         fill_c2x(t, d->c_out, d->c_in, wp_bwd, &q);
@@ -1311,12 +1326,13 @@ extern "C" int rh_conv2d_bwd_data_f32(const rh_conv2d_desc* d, const float* dy, 
             q.rows = rh_cdiv(d->h_in, d->sh); q.qcols = rh_cdiv(d->w_in, d->sw);
             q.is_h = 1; q.is_w = 1; q.os_h = d->sh; q.os_w = d->sw;
             q.out_act = RH_ACT_NONE; q.out_slope = 0.f;
+            q.in_range = in_range; q.out_range = out_range;
             bool used = false;
             if (int e = rh_conv2d_x6_launch(q, (hipStream_t)stream, "conv2d_bwd_data_x6", &used)) return e;
             if (used) return RH_OK;
         }
     }
-    return launch_conv2(p, t, (hipStream_t)stream, "conv2d_bwd_data");
+    return range_after(launch_conv2(p, t, (hipStream_t)stream, "conv2d_bwd_data"));
 }
 
 // 1 = the weight gradient of this geometry runs on the bf16 matrix cores (wgrad2d_x6.hip), 0 = f32-input MFMA kernels
@@ -1347,6 +1363,8 @@ extern "C" int64_t rh_conv2d_workspace_bytes(const rh_conv2d_desc* d) {
 extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy, const float* y, const float* x,
                                         float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                                         rh_stream_t stream_) {
+    const unsigned *dy_range = nullptr, *x_range = nullptr;
+    rh_take_ranges(&dy_range, &x_range, nullptr, nullptr);
     if (int e = validate2(d)) return e;
     hipStream_t stream = (hipStream_t)stream_;
     RH_REQUIRE(dw && (d->batch == 0 || (dy && x)), RH_ERR_INVALID, "conv2d_bwd_weight: null pointer");
@@ -1373,7 +1391,7 @@ extern "C" int rh_conv2d_bwd_weight_f32(const rh_conv2d_desc* d, const float* dy
     workspace_bytes = workspace_bytes > bias_ws ? workspace_bytes - bias_ws : 0;
     if (d->act == RH_ACT_NONE) {      // (the caller has folded act'(y) into dy) -- bf16x6 kernel where the geometry allows
         bool used = false;
-        if (int e = rh_wgrad2d_x6_launch(d, dy, x, dw, workspace, workspace_bytes, stream, &used)) return e;
+        if (int e = rh_wgrad2d_x6_launch(d, dy, x, dw, workspace, workspace_bytes, stream, &used, dy_range, x_range)) return e;
         if (used) return RH_OK;
     }
     Wgrad2P p;

@@ -29,15 +29,13 @@
 
 namespace {
 
-// This kernel keeps the three-piece bf16 scheme in every build (its operand is packed by conv2d.hip, without range records).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define RH_C2X_SA {2, 0, 1, 1, 0, 0}
-#define RH_C2X_SB {0, 2, 1, 0, 1, 0}
+// Round 6: the numerics of the build (common.hpp: two f16 pieces and three products with per-tensor scales from range slots, or
+// three bf16 pieces and six products), as conv_x6_kernel.
 
 template <int TM, int TN, int NQ>
 __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
     constexpr int BM = 32 * TM;
-    constexpr int A_UNITS = 6 * BM;                   // 16-byte fragments of one A stage: [g][piece][BM]
+    constexpr int A_UNITS = 2 * kX6P * BM;            // 16-byte fragments of one A stage: [g][piece][BM]
     constexpr int NAL = (A_UNITS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* const a_st = reinterpret_cast<u32x4*>(smem_raw);
@@ -62,6 +60,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
 
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.wq), 0, p.wq_bytes, 0x00020000);
+#if RH_X6_F16
+    // scales (common.hpp): the activations' from the producer's range slot; the weights' record and the accumulators' unscale
+    // are read in the epilogue (scalar registers are the scarce resource of the 96 x 64 wave tile)
+    int inv_b;
+    const unsigned in_max = rh_range_max(p.in_range);
+    const float xsc = __uint_as_float(rh_x6_scale_bits(in_max, &inv_b));
+#endif
 
     // ---- B fragment positions of this lane's column tiles inside the patch image
     int bpos[TN];
@@ -71,9 +76,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
         const int ql = col & (p.TQ - 1);
         const int rl = (col >> p.tq_shift) & (p.TR - 1);
         const int bl = col >> (p.tq_shift + p.tr_shift);
-        bpos[tn] = g * 3 * P + bl * PHW + rl * p.is_h * PW + ql * p.is_w;
+        bpos[tn] = g * kX6P * P + bl * PHW + rl * p.is_h * PW + ql * p.is_w;
     }
-    const int arow = g * 3 * BM + j;
+    const int arow = g * kX6P * BM + j;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
         const int gs = u / BM, mrow = u - gs * BM;
         aoff[r] = (u < A_UNITS && m0 + mrow < p.Mp) ? (unsigned)((gs * p.Mp + m0 + mrow) * 16) : kOOB;
     }
-    const unsigned step_bytes = (unsigned)(6 * p.Mp * 16);
+    const unsigned step_bytes = (unsigned)(2 * kX6P * p.Mp * 16);
 
     // ---- conversion tasks: (octet, patch position) -> element offset of the octet's first channel (chunk 0)
     const int plane = p.in_h * p.in_w;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
         const int pw_ = rem - ph_ * PW;
         const int h = h0 + ph_, w = w0 + pw_;
         const bool ok = task && b0 + bl < p.B && h >= 0 && h < p.in_h && w >= 0 && w < p.in_w;
-        xdst[q] = task ? o * 3 * P + pp : -1;
+        xdst[q] = task ? o * kX6P * P + pp : -1;
         xoff[q] = ok ? (unsigned)((((b0 + bl) * p.C + 8 * o) * plane + h * p.in_w + w) * 4) : kOOB;
     }
     const unsigned chunk_bytes = (unsigned)(16 * plane * 4);
@@ -131,6 +136,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (xdst[q] < 0) continue;
+#if RH_X6_F16
+            u32x4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const rh_h2 h = rh_h2_split(xr[q][2 * k] * xsc, xr[q][2 * k + 1] * xsc);
+                hi[k] = h.hi; lo[k] = h.lo;
+            }
+            b_st[xdst[q]] = hi;
+            b_st[xdst[q] + P] = lo;
+#else
             unsigned h[3][8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) rh_bf3_split(xr[q][i], h[0][i], h[1][i], h[2][i]);
@@ -141,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
                 for (int k = 0; k < 4; ++k) pk[k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);
                 b_st[xdst[q] + s3 * P] = pk;
             }
+#endif
         }
     };
     const int nchunks = p.C >> 4;
@@ -181,27 +197,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
                 toff_next = p.toff[tap0 + t1];
             }
             const u32x4* al = a_st + (st & 1) * A_UNITS + arow;
-            bf16x8 bfr[TN][3], afr[TM][3];
+            rh_x6_frag bfr[TN][kX6P], afr[TM][kX6P];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) bfr[tn][s3] = __builtin_bit_cast(bf16x8, b_st[bpos[tn] + s3 * P + toff]);
+                for (int s3 = 0; s3 < kX6P; ++s3) bfr[tn][s3] = __builtin_bit_cast(rh_x6_frag, b_st[bpos[tn] + s3 * P + toff]);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) afr[tm][s3] = __builtin_bit_cast(bf16x8, al[s3 * BM + tm * 32]);
+                for (int s3 = 0; s3 < kX6P; ++s3) afr[tm][s3] = __builtin_bit_cast(rh_x6_frag, al[s3 * BM + tm * 32]);
             if (st + 1 < S) {
                 store_a((st + 1) & 1);
                 if (st + 2 < S) load_a(st + 2);
             }
-            constexpr int SA[6] = RH_C2X_SA, SB[6] = RH_C2X_SB;     // smallest terms first
+            constexpr int SA[RH_X6_NPROD] = RH_X6_SA, SB[RH_X6_NPROD] = RH_X6_SB;     // smallest terms first
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < RH_X6_NPROD; ++q)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = RH_X6_MFMA(afr[tm][SA[q]], bfr[tn][SB[q]], acc[tm][tn]);
             __syncthreads();
         }
         if (ci + 1 < nchunks) {
@@ -232,13 +248,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_x6_kernel(const C2X p) {
     const auto none_r = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(nullptr), 0, 0, 0x00020000);
     const bool full = m0 + BM <= p.M;
     const int mode = (p.bias ? 1 : 0) | (p.out_act == RH_ACT_LEAKY ? 8 : 0);
-    float amax_unused = 0.f;
-#define RH_C2X_ROWS(MODE) x6_store_tile<MODE, TM, TN>(acc, cb, m0, g, p.M, full, oplane, out_r, none_r, none_r, bias_r, 1.f, p.out_slope, 1.f, amax_unused)
+    float amax = 0.f;
+#if RH_X6_F16
+    int inv_a;
+    (void)rh_x6_scale_bits(p.w_range[0], &inv_a);
+    const float osc = __uint_as_float(rh_x6_unscale_bits(inv_a, inv_b));
+#else
+    const float osc = 1.f;
+#endif
+#define RH_C2X_ROWS(MODE) x6_store_tile<MODE, TM, TN>(acc, cb, m0, g, p.M, full, oplane, out_r, none_r, none_r, bias_r, 1.f, p.out_slope, osc, amax)
     if (mode == 0) RH_C2X_ROWS(0);
     else if (mode == 1) RH_C2X_ROWS(1);
     else if (mode == 8) RH_C2X_ROWS(8);
     else RH_C2X_ROWS(9);
 #undef RH_C2X_ROWS
+    if (RH_X6_F16 && p.out_range)       // (uniform; the LDS stages are dead after the main loop's last barrier)
+        rh_range_publish(p.out_range, amax, blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u, reinterpret_cast<float*>(smem_raw));
 }
 
 bool c2x_enabled() {
@@ -262,6 +287,7 @@ struct C2XPlan {
 
 bool plan_c2x(C2X& p, C2XPlan* pl) {
     if (!c2x_enabled() || p.B <= 0 || (p.C & 15) || p.nphase < 1 || p.nphase > kPh2x) return false;
+    if (RH_X6_F16 && !p.in_range) return false;          // no range slot for the input: f32-input MFMA kernels
     if (((uintptr_t)p.wq & 15) || ((uintptr_t)p.in & 3) || ((uintptr_t)p.out & 3)) return false;
     const unsigned long long in_b = 4ull * p.B * p.C * (unsigned long long)p.in_h * p.in_w;
     const unsigned long long out_b = 4ull * p.B * p.M * (unsigned long long)p.out_h * p.out_w;
@@ -291,8 +317,10 @@ bool plan_c2x(C2X& p, C2XPlan* pl) {
         if (2 * c.P > 256 * 8) continue;
         // (96-row tiles with the 64-column wave tile AND eight conversion tasks per thread do not fit 256 VGPRs -- that
         // instance spilled 19 registers: such a patch takes the 32-column wave tile)
-        if (pl->tm == 3 && tn == 2 && 2 * c.P > 256 * 4) continue;
-        c.lds = (size_t)(2 * 6 * BM + 6 * c.P) * 16;
+        // (f16 build: the 96 x 64 wave tile runs out of SCALAR registers with the scale bookkeeping -- 236 spilled and a reserved
+        // private segment, which tests/test_abi_and_host.py rejects for the matrix-core kernels; no shipped config has a 96-row 2-D layer)
+        if (pl->tm == 3 && tn == 2 && (RH_X6_F16 || 2 * c.P > 256 * 4)) continue;
+        c.lds = (size_t)(2 * 2 * kX6P * BM + 2 * kX6P * c.P) * 16;
         if (c.lds > 160 * 1024) continue;
         // two workgroups per CU (<= 80 KB each) matter more than the larger wave tile: with one, every barrier and the
         // conversion at a chunk boundary stall the whole CU
@@ -334,13 +362,15 @@ long rh_conv2d_x6_units(int C, int M, int nphase, const int* ntaps, long* ph_ofs
     long u = 0;
     for (int ph = 0; ph < nphase; ++ph) {
         if (ph_ofs) ph_ofs[ph] = u;
-        u += (long)(C >> 4) * ntaps[ph] * 6 * Mp;
+        u += (long)(C >> 4) * ntaps[ph] * 2 * kX6P * Mp;
     }
     return u;
 }
 
 bool rh_conv2d_x6_plan_query(C2X p, long* out) {
     C2XPlan pl{};
+    static const unsigned any_range[kRangeSlotWords] = {};
+    if (!p.in_range) p.in_range = any_range;       // planning only
     if (!plan_c2x(p, &pl)) return false;
     out[0] = pl.tm; out[1] = pl.tn; out[2] = pl.nq; out[3] = p.TR; out[4] = p.TQ; out[5] = p.nb;
     out[6] = (long)pl.lds;
@@ -352,10 +382,14 @@ int rh_conv2d_x6_launch(C2X& p, hipStream_t stream, const char* what, bool* used
     *used = false;
     C2XPlan pl{};
     if (!plan_c2x(p, &pl)) return RH_OK;
+    p.w_range = p.wq + p.wq_bytes / 4;             // the range record behind the fragments (conv_host.hip / conv2d.hip packers)
 #define RH_C2X_CASE(TM_, TN_, NQ_) if (pl.tm == TM_ && pl.tn == TN_ && pl.nq == NQ_) c2x_go<TM_, TN_, NQ_>(p, pl, stream)
     RH_C2X_CASE(1, 2, 4); else RH_C2X_CASE(1, 2, 8); else RH_C2X_CASE(1, 1, 4); else RH_C2X_CASE(1, 1, 8);
     else RH_C2X_CASE(2, 2, 4); else RH_C2X_CASE(2, 2, 8); else RH_C2X_CASE(2, 1, 4); else RH_C2X_CASE(2, 1, 8);
-    else RH_C2X_CASE(3, 2, 4); else RH_C2X_CASE(3, 1, 4); else RH_C2X_CASE(3, 1, 8);
+#if !RH_X6_F16
+    else RH_C2X_CASE(3, 2, 4);
+#endif
+    else RH_C2X_CASE(3, 1, 4); else RH_C2X_CASE(3, 1, 8);
     else RH_REQUIRE(false, RH_ERR_UNSUPPORTED, "conv2d_x6: no kernel instance for tile plan (%d, %d, %d)", pl.tm, pl.tn, pl.nq);
 #undef RH_C2X_CASE
     if (int e = rh_check_launch(what)) return e;

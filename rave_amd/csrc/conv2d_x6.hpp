@@ -24,6 +24,10 @@ struct C2X {
     long ph_q2ofs[kPh2x];      // first fragment (16-byte units) of each phase in wq
     int offh[kMaxTaps], offw[kMaxTaps];
     unsigned in_bytes, wq_bytes;
+    // range slots (f16 build, common.hpp): max |in| (required), where max |out| goes (or null), the weights' record behind wq
+    const unsigned* in_range;
+    unsigned* out_range;
+    const unsigned* w_range;
     // ---- tile plan (rh_conv2d_x6_plan)
     int TQ, TR, tq_shift, tr_shift, nb;      // column tile = nb batch items x TR rows x TQ columns (powers of two)
     int tiles_q, tiles_r;

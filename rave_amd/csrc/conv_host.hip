@@ -514,9 +514,16 @@ int pack_both(const rh_conv1d_desc* d, const float* w, const float* scale, float
 
 }  // namespace
 
-int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what) {
+// w / rows / cols given: the range records of both copies are computed first (pack_range_kernel: rows = dim 0 of w)
+int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what, const float* w, long rows, long cols) {
     const long tiles = pack_tiles(a) + pack_tiles(b);
     if (tiles == 0) return RH_OK;
+    if (w && (a.range || b.range)) {
+        if (a.range && hipMemsetAsync(a.range, 0, 16, stream) != hipSuccess) return rh_check_launch(what);
+        if (b.range && hipMemsetAsync(b.range, 0, 16, stream) != hipSuccess) return rh_check_launch(what);
+        hipLaunchKernelGGL(pack_range_kernel, dim3((unsigned)rows), dim3(256), 0, stream, w, (const float*)nullptr, cols, a.range, b.range);
+        if (int e = rh_check_launch(what)) return e;
+    }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)tiles, pack_slot_groups(a, b, tiles)), dim3(256), 0, stream, a, b);
     return rh_check_launch(what);
 }

@@ -131,12 +131,13 @@ struct PackP {
     int q2a[kMaxTaps];    // mode 1: fragment offset of (phase of the slot, chunk 0, tap-in-phase of the slot)
     int q2n[kMaxTaps];    // mode 1: fragments per chunk in the phase of the slot (ntaps * 6 * Mp)
 };
-int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what);
+int rh_pack_launch(const PackP& a, const PackP& b, hipStream_t stream, const char* what, const float* w = nullptr, long rows = 0,
+                   long cols = 0);
 // dbias[m] = sum_{b,e} dy[b][m][e] * act'(y[b][m][e]) (y may be null): grid (M, 64) partials in `part`
 // (rh_bias_grad_workspace(M) bytes) + ordered finalize -> deterministic
 int64_t rh_bias_grad_workspace(int M);
 int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db, int B, int M, long plane, int act,
-                        float slope, hipStream_t stream, float* g_out = nullptr);
+                        float slope, hipStream_t stream, float* g_out = nullptr, unsigned* g_range = nullptr);
 int rh_reduce_partials_launch(const float* part, float* out, long n, int Z, hipStream_t stream, const char* what);
 // weight norm behind a weight gradient: the caller wants dv, dg of w = g v/||v|| (dim 0) instead of dw
 struct RhWnTail {

@@ -256,10 +256,14 @@ constexpr int kBiasSlices = 64;
 
 // g_out (optional): the same pass also WRITES g = dy * act'(y) -- the operand the data- and weight-gradient kernels of a
 // conv with an output activation take -- so that one sweep replaces act_bwd_kernel (dy, y -> g) + this kernel (g -> sums).
+// g_range (optional, with g_out): max |g| goes to that range slot (common.hpp: the scale of the f16 matrix-core kernels that read
+// g next) -- one atomic per workgroup, M x 64 of them; saves the separate rh_amax_f32 pass over g (4.8 ms of a discrete-config step).
 __global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           float* __restrict__ part, int B, int M, long plane, int act,
-                                                          float slope, float* __restrict__ g_out) {
+                                                          float slope, float* __restrict__ g_out, unsigned* __restrict__ g_range) {
     __shared__ float red[4];
+    __shared__ float red_max[4];
+    float mx = 0.f;
     const int m = blockIdx.x, sl = blockIdx.y;
     const long segs_per_b = (plane + 1023) / 1024;
     const long nseg = (long)B * segs_per_b;
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restric
                 float v = dy[base + e];
                 if (y) v *= rh_act_grad(y[base + e], act, slope, 0.f);
                 if (g_out) g_out[base + e] = v;
+                mx = fmaxf(mx, fabsf(v));
                 s += v;
             }
         }
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(256) void bias_grad2d_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) part[(long)m * kBiasSlices + sl] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (g_range) rh_range_publish(g_range, mx, blockIdx.x + blockIdx.y * 7u, red_max);      // (uniform)
 }
 
 __global__ __launch_bounds__(64) void bias_grad2d_finalize_kernel(const float* __restrict__ part, float* __restrict__ db,
@@ -849,8 +855,9 @@ extern "C" int64_t rh_conv1d_bwd_weight_wn_fused_launches(void) { return g_rwn_l
 int64_t rh_bias_grad_workspace(int M) { return (int64_t)M * kBiasSlices * (int64_t)sizeof(float); }
 
 int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db, int B, int M, long plane, int act,
-                        float slope, hipStream_t stream, float* g_out) {
-    hipLaunchKernelGGL(bias_grad2d_kernel, dim3(M, kBiasSlices), dim3(256), 0, stream, dy, y, part, B, M, plane, act, slope, g_out);
+                        float slope, hipStream_t stream, float* g_out, unsigned* g_range) {
+    hipLaunchKernelGGL(bias_grad2d_kernel, dim3(M, kBiasSlices), dim3(256), 0, stream, dy, y, part, B, M, plane, act, slope, g_out,
+                       g_out ? g_range : nullptr);
     if (int e = rh_check_launch("bias_grad")) return e;
     hipLaunchKernelGGL(bias_grad2d_finalize_kernel, dim3(rh_cdiv(M, 64)), dim3(64), 0, stream, (const float*)part, db, M);
     return rh_check_launch("bias_grad_finalize");
@@ -862,9 +869,11 @@ int rh_bias_grad_launch(const float* dy, const float* y, float* part, float* db,
 extern "C" int64_t rh_act_bwd_bias_workspace_bytes(int32_t M) { return rh_bias_grad_workspace(M); }
 extern "C" int rh_act_bwd_bias_f32(const float* dy, const float* y, int32_t act, float slope, int32_t B, int32_t M, int64_t plane,
                                    float* g, float* dbias, void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    unsigned* g_range = nullptr;                       // where max |g| goes, if the caller armed an output slot (rh_x6_set_ranges)
+    rh_take_ranges(nullptr, nullptr, &g_range, nullptr);
     RH_REQUIRE(dy && y && g && dbias && B >= 0 && M > 0 && plane > 0, RH_ERR_INVALID, "act_bwd_bias: bad arguments");
     RH_REQUIRE(act == RH_ACT_NONE || act == RH_ACT_LEAKY, RH_ERR_UNSUPPORTED, "act_bwd_bias: activation must be none or leaky");
     RH_REQUIRE(workspace && workspace_bytes >= rh_bias_grad_workspace(M), RH_ERR_WORKSPACE, "act_bwd_bias: workspace too small");
     if (B == 0) return hipMemsetAsync(dbias, 0, (size_t)M * sizeof(float), (hipStream_t)stream) == hipSuccess ? RH_OK : RH_ERR_INVALID;
-    return rh_bias_grad_launch(dy, y, (float*)workspace, dbias, B, M, plane, act, slope, (hipStream_t)stream, g);
+    return rh_bias_grad_launch(dy, y, (float*)workspace, dbias, B, M, plane, act, slope, (hipStream_t)stream, g, g_range);
 }

@@ -329,7 +329,6 @@ int rh_conv_launch_x6(ConvP& p, hipStream_t stream, const char* what, void* ws, 
 // on the f32 kernels.
 namespace {
 bool fill_c2x_from_1d(const ConvP& p, C2X* q) {
-    if (RH_X6_F16) return false;      // the 1-D operand holds f16 pieces in this build; the 2-D kernel multiplies bf16 ones
     if (p.x6_mode != 1 || p.is == 1 || p.is == 2 || p.is == 4 || p.inner != 1 || p.nphase != 1 || p.os != 1) return false;
     if (p.in_act != RH_ACT_NONE || p.epi_act != RH_ACT_NONE || p.mul_src || p.add || p.in_alpha || p.mul_alpha) return false;
     if (p.in_row != p.in_valid || p.out_row != p.out_valid || p.ph_ntaps[0] < 1 || p.ph_ntaps[0] > kMaxTaps) return false;
@@ -347,6 +346,7 @@ bool fill_c2x_from_1d(const ConvP& p, C2X* q) {
     q->ph_q2ofs[0] = p.ph_q2ofs[0];
     for (int t = 0; t < p.ph_ntaps[0]; ++t) { q->offh[t] = p.off[p.ph_tap0[0] + t]; q->offw[t] = 0; }
     q->wq_bytes = p.wq_bytes;
+    q->in_range = p.in_range; q->out_range = p.out_range;      // (f16 build; the weights' record sits behind the fragments of both packers)
     return true;
 }
 }  // namespace

@@ -35,7 +35,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int kW2Waves = 8, kW2Threads = 512;
@@ -58,6 +57,8 @@ struct W2X {
     int minh, minw;
     int ngt, nxt;                  // conversion tasks of one tile: G, X
     unsigned g_bytes, x_bytes;
+    const unsigned* g_range;       // range slots of G and X (f16 build: common.hpp)
+    const unsigned* x_range;
     int toff[kW2MaxTaps];          // element offset of a tap inside a channel's patch image
 };
 
@@ -71,9 +72,9 @@ template <int NQX, int SW>
 __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) {
     constexpr int XL = 8 * SW;                        // input columns one X task loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned short* const g_img = reinterpret_cast<unsigned short*>(smem_raw);               // [3][32][gp]
-    unsigned short* const x_img = g_img + 3 * 32 * p.gp;                                      // [3][32][xp]
-    int* const toff_s = reinterpret_cast<int*>(x_img + 3 * 32 * p.xp);                        // [kW2MaxTaps]
+    unsigned short* const g_img = reinterpret_cast<unsigned short*>(smem_raw);               // [piece][32][gp]
+    unsigned short* const x_img = g_img + kX6P * 32 * p.gp;                                   // [piece][32][xp]
+    int* const toff_s = reinterpret_cast<int*>(x_img + kX6P * 32 * p.xp);                     // [kW2MaxTaps]
     const unsigned g_base = (unsigned)(size_t)g_img, x_base = (unsigned)(size_t)x_img;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
 
     const auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
     const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+#if RH_X6_F16
+    // scales (common.hpp): both operands are activations -- from their producers' range slots
+    int inv_g, inv_x;
+    const float gsc = __uint_as_float(rh_x6_scale_bits(rh_range_max(p.g_range), &inv_g));
+    const float xsc = __uint_as_float(rh_x6_scale_bits(rh_range_max(p.x_range), &inv_x));
+    const float osc = __uint_as_float(rh_x6_unscale_bits(inv_g, inv_x));
+#else
+    const float gsc = 1.f, xsc = 1.f, osc = 1.f;
+#endif
 
     f32x16 acc[4];
 #pragma unroll
@@ -146,7 +156,18 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
                     x_rsrc, (ok && w + i >= 0 && w + i < p.s_w) ? base + 4u * i : kOOB, 0, 0));
         }
     };
-    auto split_store = [&](const float (&v)[8], unsigned short* dst, int piece_stride) {
+    auto split_store = [&](const float (&v)[8], float sc, unsigned short* dst, int piece_stride) {
+#if RH_X6_F16
+        u32x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const rh_h2 h = rh_h2_split(v[2 * k] * sc, v[2 * k + 1] * sc);
+            hi[k] = h.hi; lo[k] = h.lo;
+        }
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + piece_stride) = lo;
+#else
+        (void)sc;
         unsigned h[3][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -162,9 +183,10 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
             for (int k = 0; k < 4; ++k) pk[k] = __builtin_amdgcn_perm(h[s3][2 * k + 1], h[s3][2 * k], 0x07060302u);
             *reinterpret_cast<u32x4*>(dst + s3 * piece_stride) = pk;
         }
+#endif
     };
     auto convert_tile = [&]() {
-        if (gt_task) split_store(gr, g_img + gt_m * p.gp + gt_r * TQ + 8 * gt_f, 32 * p.gp);
+        if (gt_task) split_store(gr, gsc, g_img + gt_m * p.gp + gt_r * TQ + 8 * gt_f, 32 * p.gp);
 #pragma unroll
         for (int q = 0; q < NQX; ++q) {
             if (xt_c[q] < 0) continue;
@@ -173,13 +195,13 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = xr[q][i];
-                split_store(v, dst, 32 * p.xp);
+                split_store(v, xsc, dst, 32 * p.xp);
             } else {      // even input columns -> parity plane 0, odd -> plane 1 (PH * PWp elements further)
                 float ve[8], vo[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { ve[i] = xr[q][2 * i]; vo[i] = xr[q][2 * i + 1]; }
-                split_store(ve, dst, 32 * p.xp);
-                split_store(vo, dst + p.PH * PWp, 32 * p.xp);
+                split_store(ve, xsc, dst, 32 * p.xp);
+                split_store(vo, xsc, dst + p.PH * PWp, 32 * p.xp);
             }
         }
     };
@@ -214,20 +236,31 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
             // K block kb = tile positions 16 kb .. 16 kb + 15 (row-major over TR x TQ); this lane's fragment starts at
             // position 16 kb + 8 g = (row, column) of the tile -- a fragment never straddles a row (TQ is a multiple of 8)
             const unsigned ao = a_lane + 2u * (unsigned)(16 * kb);
-            u32x4 a0 = lds_read_b128_any(ao), a1 = lds_read_b128_any(ao + a_piece), a2 = lds_read_b128_any(ao + 2 * a_piece);
+            u32x4 av[kX6P];
+#pragma unroll
+            for (int s3 = 0; s3 < kX6P; ++s3) av[s3] = lds_read_b128_any(ao + s3 * a_piece);
             const int pos = 16 * kb + 8 * g;
             const unsigned bo = x_base + 2u * (unsigned)((pos >> p.tq_shift) * p.sh * PWp + (pos & (TQ - 1)));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (wave + kW2Waves * i >= ntile) break;               // wave-uniform
-                u32x4 b0 = lds_read_b128_any(bo + boff[i]), b1 = lds_read_b128_any(bo + boff[i] + b_piece),
-                      b2 = lds_read_b128_any(bo + boff[i] + 2 * b_piece);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
-                const bf16x8 af[3] = {__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, a2)};
-                const bf16x8 bf[3] = {__builtin_bit_cast(bf16x8, b0), __builtin_bit_cast(bf16x8, b1), __builtin_bit_cast(bf16x8, b2)};
-                constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+                u32x4 bv[kX6P];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SA[q]], bf[SB[q]], acc[i], 0, 0, 0);
+                for (int s3 = 0; s3 < kX6P; ++s3) bv[s3] = lds_read_b128_any(bo + boff[i] + s3 * b_piece);
+#if RH_X6_F16
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]));
+#else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]));
+#endif
+                rh_x6_frag af[kX6P], bf[kX6P];
+#pragma unroll
+                for (int s3 = 0; s3 < kX6P; ++s3) {
+                    af[s3] = __builtin_bit_cast(rh_x6_frag, av[s3]);
+                    bf[s3] = __builtin_bit_cast(rh_x6_frag, bv[s3]);
+                }
+                constexpr int SA[RH_X6_NPROD] = RH_X6_SA, SB[RH_X6_NPROD] = RH_X6_SB;     // smallest terms first
+#pragma unroll
+                for (int q = 0; q < RH_X6_NPROD; ++q) acc[i] = RH_X6_MFMA(af[SA[q]], bf[SB[q]], acc[i]);
             }
         }
     }
@@ -241,7 +274,7 @@ __global__ __launch_bounds__(kW2Threads, 1) void wgrad2d_x6_kernel(const W2X p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 4 * g + (r & 3) + 8 * (r >> 2);
-            if (m < p.M) part[m * CT + (long)(c0 + col_c[i]) * p.T + col_t[i]] = acc[i][r];
+            if (m < p.M) part[m * CT + (long)(c0 + col_c[i]) * p.T + col_t[i]] = RH_X6_F16 ? acc[i][r] * osc : acc[i][r];
         }
     }
 }
@@ -288,7 +321,7 @@ bool plan_w2x(const rh_conv2d_desc* d, W2X* p, W2XPlan* pl) {
         p->gp = (TR * TQ) | 8;                          // 16-byte slots per row image: odd -> lanes (rows) spread over the banks
         p->xp = d->sw * p->PH * p->PWp;
         if (((p->xp >> 3) & 1) == 0) p->xp += 8;
-        pl->lds = (size_t)3 * 32 * ((size_t)p->gp + p->xp) * 2 + kW2MaxTaps * 4;
+        pl->lds = (size_t)kX6P * 32 * ((size_t)p->gp + p->xp) * 2 + kW2MaxTaps * 4;
         p->ngt = 32 * TR * (TQ / 8);
         p->nxt = cg * p->PH * (p->PWp >> 3);
         if (pl->lds <= 160 * 1024 && p->ngt <= kW2Threads && p->nxt <= kW2Threads * (d->sw == 1 ? 6 : 3)) break;
@@ -343,11 +376,13 @@ int64_t rh_wgrad2d_x6_workspace(const rh_conv2d_desc* d) {
 // dw = sum over positions of dy (x) x-patches; dy already carries act'(y).  *used = false when the geometry (or the scratch
 // offered) does not fit.
 int rh_wgrad2d_x6_launch(const rh_conv2d_desc* d, const float* dy, const float* x, float* dw, void* ws, int64_t ws_bytes,
-                         hipStream_t stream, bool* used) {
+                         hipStream_t stream, bool* used, const unsigned* dy_range, const unsigned* x_range) {
     *used = false;
     W2X p;
     W2XPlan pl{};
+    if (RH_X6_F16 && (!dy_range || !x_range)) return RH_OK;      // no range slots (rh_x6_set_ranges): f32-input MFMA kernels
     if (!plan_w2x(d, &p, &pl)) return RH_OK;
+    p.g_range = dy_range; p.x_range = x_range;
     const long nw = (long)d->c_out * d->c_in * d->kh * d->kw;
     const int64_t need = (int64_t)pl.Z * nw * (int64_t)sizeof(float);
     if (((uintptr_t)dy & 3) || ((uintptr_t)x & 3)) return RH_OK;

@@ -990,6 +990,17 @@ def _launch2(kind: str, d, fn):
     return _timed(kind, f, b, fn)
 
 
+def _conv2d_ranges(d, which: int, t: Tensor, dev, s, tag: str):
+    """(input slot, output slot) of a 2-D forward (which = 0) / data-gradient (1) launch in the f16 build: the input's only where
+    the matrix-core kernel (conv2d_x6.hip, family 1) will read it, the output's always (every kernel family fills it)."""
+    if not _ranges_on():
+        return None, None
+    info = (C.c_int64 * 16)()
+    fam = int(info[0]) if L.lib.rh_conv2d_plan_info(C.byref(d), which, info) == 0 else 0
+    rin = _range_of(t, s, tag) if fam == 1 else None
+    return rin, _new_range(dev)
+
+
 class _Conv2dFn(torch.autograd.Function):
     """y = act(conv2d(x, w) + bias) with zero padding (rh_conv2d_*_f32): torch.nn.Conv2d followed by the
     LeakyReLU the reference's discriminators put after it (rave/discriminator.py:23-51,
@@ -1020,8 +1031,15 @@ class _Conv2dFn(torch.autograd.Function):
             if ctx.needs_input_grad[0] else None
         L.check(L.lib.rh_conv2d_pack_f32(dref, L.ptr(weight), L.ptr(wp_f), L.ptr(wp_b), s), "conv2d_pack")
         y = torch.empty(b, c_out, h_out, w_out, device=dev, dtype=torch.float32)
-        L.check(_launch2("conv2d_fwd", d, lambda: L.lib.rh_conv2d_fwd_f32(dref, L.ptr(x), L.ptr(wp_f), L.ptr(bias), L.ptr(y), s)),
-                "conv2d_fwd")
+        rin, rout = _conv2d_ranges(d, 0, x, dev, s, "conv2d x")
+
+        def run_fwd():
+            if rout is not None:
+                L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(rout), None)
+            return L.lib.rh_conv2d_fwd_f32(dref, L.ptr(x), L.ptr(wp_f), L.ptr(bias), L.ptr(y), s)
+
+        L.check(_launch2("conv2d_fwd", d, run_fwd), "conv2d_fwd")
+        _attach_range(y, rout)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, wp_b)
         ctx.d = d
         ctx.wshape = tuple(weight.shape)
@@ -1044,8 +1062,12 @@ class _Conv2dFn(torch.autograd.Function):
                 db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
                 nb = L.lib.rh_act_bwd_bias_workspace_bytes(d.c_out)
                 wsb = torch.empty(max(nb, 4) // 4, device=dy.device, dtype=torch.float32)
+                rg = _new_range(dy.device) if _ranges_on() else None     # the same sweep leaves max |g| for the f16 kernels
+                if rg is not None:
+                    L.lib.rh_x6_set_ranges(None, None, L.ptr(rg), None)
                 L.check(L.lib.rh_act_bwd_bias_f32(L.ptr(dy), L.ptr(y), d.act, d.act_slope, d.batch, d.c_out, d.h_out * d.w_out,
                                                   L.ptr(g), L.ptr(db), L.ptr(wsb), nb, s), "act_bwd_bias")
+                _attach_range(g, rg)
                 need_b = False
             else:
                 L.check(L.lib.rh_act_bwd_f32(L.ptr(dy), L.ptr(y), d.act, d.act_slope, dy.numel(), L.ptr(g), s), "act_bwd")
@@ -1055,17 +1077,33 @@ class _Conv2dFn(torch.autograd.Function):
         dref = C.byref(d)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(_launch2("conv2d_dgrad", d, lambda: L.lib.rh_conv2d_bwd_data_f32(
-                dref, L.ptr(dy), L.ptr(y), L.ptr(wp_b), L.ptr(dx), s)), "conv2d_bwd_data")
+            rin, rout = _conv2d_ranges(d, 1, dy, dy.device, s, "conv2d dy") if y is None else (None, None)
+
+            def run_dgrad():
+                if rout is not None:
+                    L.lib.rh_x6_set_ranges(None, L.ptr(rin), L.ptr(rout), None)
+                return L.lib.rh_conv2d_bwd_data_f32(dref, L.ptr(dy), L.ptr(y), L.ptr(wp_b), L.ptr(dx), s)
+
+            L.check(_launch2("conv2d_dgrad", d, run_dgrad), "conv2d_bwd_data")
+            _attach_range(dx, rout)
         if ctx.needs_input_grad[1] or need_b:
             dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
             if need_b:
                 db = torch.empty(d.c_out, device=dy.device, dtype=torch.float32)
             nbytes = L.lib.rh_conv2d_workspace_bytes(dref)
             ws = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
-            L.check(_launch2("conv2d_wgrad", d, lambda: L.lib.rh_conv2d_bwd_weight_f32(
-                dref, L.ptr(dy), L.ptr(y), L.ptr(x), L.ptr(dw), L.ptr(db) if need_b else None, L.ptr(ws), nbytes, s)),
-                "conv2d_bwd_weight")
+            # the f16 weight-gradient kernel (wgrad2d_x6.hip) scales both operands by their tensors' ranges
+            use_r = _ranges_on() and y is None and L.lib.rh_conv2d_bwd_weight_kernel_family(dref) == 1
+            rdy = _range_of(dy, s, "conv2d wgrad dy") if use_r else None
+            rx = _range_of(x, s, "conv2d wgrad x") if use_r else None
+
+            def run_wgrad():
+                if use_r:
+                    L.lib.rh_x6_set_ranges(L.ptr(rdy), L.ptr(rx), None, None)
+                return L.lib.rh_conv2d_bwd_weight_f32(dref, L.ptr(dy), L.ptr(y), L.ptr(x), L.ptr(dw), L.ptr(db) if need_b else None,
+                                                      L.ptr(ws), nbytes, s)
+
+            L.check(_launch2("conv2d_wgrad", d, run_wgrad), "conv2d_bwd_weight")
         return dx, dw, db, None, None, None, None, None
 
 

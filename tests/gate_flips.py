@@ -147,3 +147,30 @@ def feature_map_flips(got_feats, ref_feats, model):
                 if pid in names:
                     down[names[pid]] += n
     return down, total_flips, total
+
+
+def feature_map_flip_effects(got_feats, ref_feats, model, grad_feats, factor: float = 0.9):
+    """Discriminators: the first-order size of what the counted flips do to each parameter gradient.  ``grad_feats`` = the
+    feature maps of an evaluation whose maps RETAINED their gradients (``f.retain_grad()`` before its backward pass; the tests
+    pass the fp32 oracle's -- the HIP modules hand out re-laid-out views of their maps, which are not on the gradient's path):
+    a flipped LeakyReLU gate on element e of map f multiplies the gradient that flows back through e by slope^(+-1), i.e.
+    changes it by at most ``factor`` = 1 - slope (0.9 bounds the slopes 0.1 and 0.2 in use) of |dL/df[e]| -- relative to the norm
+    of the whole gradient that leaves the map, ||dL/df * act'||.  With the sparse hinge cotangent of a discriminator step a single
+    element can carry percents of that norm, which a numel-based estimate (0.9 / sqrt(numel)) misses by an order of magnitude.
+    Returns {parameter name: sum over the flipped gates downstream of it of that relative change} (0 without a flip)."""
+    names = {id(p): k for k, p in model.named_parameters()}
+    out = {k: 0.0 for k in names.values()}
+    for net, rnet, gnet in zip(got_feats, ref_feats, grad_feats):
+        for f, rf, gf in zip(net[:-1], rnet[:-1], gnet[:-1]):
+            d = (f.detach().cpu() > 0) != (rf.detach().cpu() > 0)
+            if not bool(d.any()):
+                continue
+            assert gf.grad is not None, "feature_map_flip_effects: the maps of grad_feats did not retain their gradients"
+            g = gf.grad.detach().cpu().double()
+            slope = torch.where(gf.detach().cpu() > 0, torch.ones_like(g), torch.full_like(g, 1.0 - factor))
+            through = float((g * slope).norm())
+            eff = factor * float(g[d].abs().sum()) / max(through, 1e-300)
+            for pid in params_upstream_of(f):
+                if pid in names:
+                    out[names[pid]] += eff
+    return out

@@ -456,7 +456,10 @@ def test_conv2d_x6_tile_plans_cover_every_geometry():
                     if cin % 16:
                         assert fam == 0 and packed == base
                         continue
-                    assert packed == base * 5 // 2                      # + 6 bytes per weight of bf16 fragments
+                    # + the matrix-core fragments (two f16 pieces = 4 bytes per weight; the comparison build: three bf16 pieces = 6)
+                    # + the 16-byte range record behind them
+                    frag = base if L.lib.rh_x6_uses_ranges() == 1 else base // 2 * 3
+                    assert packed == base + frag + 4
                     if fam == 0:          # tensors beyond the 2 GiB buffer descriptors, or no tile fits
                         assert 4 * batch * max(ci * h * w, co * ho * wo) >= 2 ** 31 - 1 or P == 0
                         continue
@@ -466,7 +469,8 @@ def test_conv2d_x6_tile_plans_cover_every_geometry():
                     assert TR * TQ * nb == 128 * tn and TQ <= 32
                     assert tiles_r * TR >= rows and tiles_q * TQ >= qcols and (tiles_r - 1) * TR < rows and (tiles_q - 1) * TQ < qcols
                     assert 2 * P <= 256 * nq and P == nb * PH * PW
-                    assert lds == (2 * 6 * 32 * tm + 6 * P) * 16 and lds <= 160 * 1024
+                    pieces = 2 if L.lib.rh_x6_uses_ranges() == 1 else 3          # 16-byte fragments per octet (common.hpp: kX6P)
+                    assert lds == (2 * 2 * pieces * 32 * tm + 2 * pieces * P) * 16 and lds <= 160 * 1024
                     is_h, is_w = (sh, sw) if which == 0 else (1, 1)
                     # the farthest fragment a lane reads: last row / column of the tile + the largest tap offset
                     assert (nb - 1) * PH * PW + (TR - 1) * is_h * PW + (TQ - 1) * is_w + maxoff < P

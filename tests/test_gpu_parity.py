@@ -1610,6 +1610,9 @@ def _hinge_step_vs_oracle(dev, model, feats_ref_fn, xy, tol=5e-4):
     ref_loss = hinge(ref_feats)
     scores = [net[-1] for net in ref_feats]
     cots = torch.autograd.grad(ref_loss, scores, retain_graph=True)
+    for net in ref_feats:                   # (the gradients at the gates: what a flipped gate is worth, gate_flips.py)
+        for f in net[:-1]:
+            f.retain_grad()
     torch.autograd.backward(scores, cots)
     leaves64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
     f64 = feats_ref_fn(xy.double(), leaves64)
@@ -1631,9 +1634,12 @@ def _hinge_step_vs_oracle(dev, model, feats_ref_fn, xy, tol=5e-4):
     # (tests/gate_flips.py: sign masks of the feature maps of this run against the fp64 evaluation the gradients are
     # compared with; upstream parameters from the autograd graph): a gradient outside the tight bound must have at
     # least one flipped gate downstream of its layer -- equivalently, no tensor whose downstream gates all agree with
-    # the fp64 run may be outside it.  Everything stays within 3e-3 (a handful of flips).
-    from gate_flips import feature_map_flips
+    # the fp64 run may be outside it.  How far outside is bounded by what the counted flips are WORTH: 3 x the first-order
+    # change of the gradient through the flipped elements (gate_flips.feature_map_flip_effects: from the gradients at the
+    # gates of the fp32 oracle's evaluation), on top of the 3e-3 everything else stays within.
+    from gate_flips import feature_map_flips, feature_map_flip_effects
     down, n_flips, n_gates = feature_map_flips(got_feats, f64, model)
+    effect = feature_map_flip_effects(got_feats, f64, model, ref_feats)
     bad, loose, unexplained, checked = [], [], [], 0
     for k, p in model.named_parameters():
         want = leaves64[k].grad
@@ -1648,8 +1654,8 @@ def _hinge_step_vs_oracle(dev, model, feats_ref_fn, xy, tol=5e-4):
             bad.append((k, err / max(norm, 1e-30), ref_err / max(norm, 1e-30), down[k]))
             if down[k] == 0:
                 unexplained.append(bad[-1])
-        if err > max(3e-3 * norm, 3.0 * ref_err) + 1e-6:
-            loose.append((k, err, ref_err, norm))
+        if err > max((3e-3 + 3.0 * effect[k]) * norm, 3.0 * ref_err) + 1e-6:
+            loose.append((k, err, ref_err, norm, effect[k]))
         checked += 1
     print(f"gate flips vs the fp64 evaluation: {n_flips} of {n_gates} gate elements; {len(bad)} of {checked} gradients "
           f"outside the tight bound, all downstream-explained: {not unexplained}")
