@@ -597,13 +597,46 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / nf
 
+        def time_fwd_graph(nf=20):
+            """The same forward recorded once into a hipGraph and replayed (the eager loop above pays ~50 Python-side launches per
+            pass, which the GPU side of this leg -- 52 kernels of 20-60 us -- does not always hide)."""
+            from rave_amd import ops as R
+            m.prepare_weights(reuse=True)
+            m.set_phase_flags_eagerly()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                R.range_reset(x.device)
+                yy = m.decode(m.encoder.reparametrize(m.encode(x))[0])
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(nf):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(yy).all())
+            m.release_weights()
+            return e0.elapsed_time(e1) * 1e-3 / nf
+
         with torch.no_grad():
             m.prepare_weights(reuse=True)
             t_fwd_prep = time_fwd(True)
-            t_fwd = time_fwd(False)
+            t_fwd_eager = t_fwd = time_fwd(False)
+            fwd_mode = "eager"
+            if use_graph:
+                try:
+                    t_fwd_graph = time_fwd_graph()
+                    if t_fwd_graph < t_fwd:
+                        t_fwd, fwd_mode = t_fwd_graph, "hipGraph replay"
+                except Exception as e:                  # noqa: BLE001 -- secondary leg
+                    fwd_mode = f"eager (forward capture failed: {type(e).__name__}: {str(e)[:120]})"
         fb = args.batch * V2_FWD_ACT_BYTES_PER_CLIP * (args.n_signal / 65536) + V2_WEIGHT_BYTES
         ff = 2.0 * args.batch * V2_FWD_MAC_PER_CLIP * (args.n_signal / 65536)
-        out["forward_only"] = {"ms": t_fwd * 1e3, "ms_with_weight_prep": t_fwd_prep * 1e3,
+        out["forward_only"] = {"ms": t_fwd * 1e3, "mode": fwd_mode, "ms_eager": t_fwd_eager * 1e3,
+                               "ms_with_weight_prep": t_fwd_prep * 1e3,
                                "note": "inference forward (no_grad): packed weights reused while no parameter changed; "
                                        "ms_with_weight_prep = the same with weight norm + repack of all 56 layers forced per call",
                                "algorithmic_bytes": fb, "algorithmic_flop": ff,

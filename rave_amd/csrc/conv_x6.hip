@@ -179,7 +179,12 @@ bool plan_x6(ConvP& p, X6Plan* pl) {
     // ... for the short reductions only (pointwise and k = 3 convs at few channels: <= 64 steps): with a long K loop
     // per tile the split's fixed cost is small and the larger wave tile wins (measured per layer, profiles/)
     const int total_steps = ((p.C * is) >> 4) * (is == 1 ? p.ph_ntaps[0] : p.x6_nu);
-    if (pl->tm >= 2 && (tn_env == 1 || (tn_env == 0 && blocks < 384 && total_steps <= 64))) {
+    // (round 6, two f16 pieces: half the matrix work per tile, so the fixed costs weigh more -- launches with at most 64 tiles of the
+    // large shape (the C = 768 units, 768 <-> 1536: 2048 or 1024 columns) take the 32-column wave tile whatever the reduction
+    // length: K is cut into 4 slices instead of 8, half the partial sums to dump and re-read.  Measured per layer, RH_X6_TN=1
+    // against the default: C = 768 k = 3 48.8 -> 41.6 us forward / 50.0 -> 42.8 data gradient, 768 -> 1536 57.3 -> 52.8 / 55.6 -> 53.2,
+    // 1536 -> 768 61.1 -> 53.4 / 57.5 -> 54.2; the 128-tile launches (C = 384) lose with it and keep the 64-column tile)
+    if (pl->tm >= 2 && (tn_env == 1 || (tn_env == 0 && ((blocks < 384 && total_steps <= 64) || blocks <= 64)))) {
         const int b1 = shape(1, wm0);
         if (b1 == 0) blocks = shape(2, wm0);
         else blocks = b1;
