@@ -157,7 +157,9 @@ def test_batch32_dispatch_x6_vs_exact_f32_kernels(dev):
             assert down[k] >= 1, (k, e, "outside the tight bound without a flipped gate downstream")
         # ... and by no more than the flips downstream of it account for (gate_flips.flip_allowance_by_param: 0.8 x
         # sqrt(sum flips_j / numel_j), x3 -- round 6, VERDICT r5 weak #1a: no fixed 5e-3 any more)
-        assert e < tight + 3.0 * allow[k], (k, e, allow[k], down[k])
+        # (a gain's gradient <dw, v> / ||v|| is a projection with heavy cancellation: whatever moves dw moves it ~5x as much in
+        # relative terms -- the factor between the two tight bounds above applies to the flip allowance just the same)
+        assert e < tight + (5.0 if kind == "g" else 1.0) * 3.0 * allow[k], (k, e, allow[k], down[k])
         n += 1
     assert n == 112, n
     del gates1, gates0
