@@ -299,8 +299,7 @@ def main():
                          "bucket all-reduces into the same graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-graph", action="store_true",
-                    help="discrete config: try to record the step into a hipGraph anyway (segfaults inside "
-                         "hipStreamEndCapture on ROCm 7.2: see the note at use_graph)")
+                    help="(no-op since round 6: every config records its step; kept for old command lines)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-products-leg", action="store_true",
                     help="skip the secondary forward_only_bf16x6 leg (comparison build: 3 bf16 pieces, 6 products)")
@@ -365,11 +364,13 @@ def main():
     ddp.broadcast_module(m)
     use_ddp = world > 1 or force_dist
     # (the discrete config initialises its RVQ codebooks with k-means inside its first training step: host-driven,
-    # data-dependent work that a recorded graph cannot contain -- those steps run eagerly BEFORE the capture, below.
-    # Recording the whole discrete step still fails on this ROCm: hipStreamEndCapture segfaults inside the runtime although
-    # every component of the step -- RVQ, Encodec nets, torch.stft, MSD, the encoder -- captures and replays on its own,
-    # profiles/round4_discrete_capture_bisect.txt; so the discrete config runs eagerly unless --force-graph)
-    use_graph = not args.no_graph and (args.config != "discrete" or args.force_graph)
+    # data-dependent work that a recorded graph cannot contain -- those steps run eagerly BEFORE the capture, below, and ON A
+    # SIDE STREAM: rounds 4-5 ran them on the default stream and hipStreamEndCapture then segfaulted inside the runtime although
+    # every component of the step captured on its own (profiles/round4_discrete_capture_bisect.txt).  Round 6
+    # (tools/debug/capture_bisect2.py, profiles/round6_discrete_capture_bisect.txt): ANY eager GAN-phase step on the legacy
+    # default stream before the recording -- the plain v2 config too -- kills the capture; the same steps on a side stream,
+    # or none, and every config records.  --no-graph gives the eager step.)
+    use_graph = not args.no_graph
     gen_opt, dis_opt = m.configure_optimizers(capturable=use_graph)
     m.warmed_up = args.phase == "gan"
     m.skip_dead_grads = bool(args.skip_dead_grads)
@@ -411,11 +412,15 @@ def main():
     if use_graph and args.config == "discrete":
         # eager steps until every codebook is initialised (one of each step kind): GraphedTrainingStep refuses an
         # un-initialised RVQ (rave_amd/model.py: _check_capturable)
-        for i in range(2 if m.warmed_up else 1):
-            if use_ddp:
-                bufsync.sync()
-            m.training_step(x.detach().clone(), i, capture_safe=True, **sync_kw)
-            m.on_train_batch_end(None, None, i)
+        pre = torch.cuda.Stream()
+        pre.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(pre):          # NOT the default stream: see the note at use_graph
+            for i in range(2 if m.warmed_up else 1):
+                if use_ddp:
+                    bufsync.sync()
+                m.training_step(x.detach().clone(), i, capture_safe=True, **sync_kw)
+                m.on_train_batch_end(None, None, i)
+        torch.cuda.current_stream().wait_stream(pre)
         torch.cuda.synchronize()
     if use_graph:
         try:
