@@ -1,6 +1,7 @@
 // Host side of the bf16x6 convolution path (kernels: conv_x6_kernel.inc): tile / split-K plan and launch.
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include "conv_params.hpp"
 #include "conv2d_x6.hpp"
 
@@ -58,27 +59,31 @@ X6Launch x6_launcher(int is, int tm, int tn, int wm) {
 }
 // Arrival counters of the K-split launches (x6_combine): one word per output tile, zero whenever no launch that uses it is in
 // flight (the last arriver of a tile resets it).  A launch takes the next segment of ONE pool allocated (and zeroed) on first use
-// -- planning calls come first, so never under stream capture -- : launches that may overlap (two streams, graph branches) get
+// PER DEVICE -- planning calls come first, so never under stream capture -- : launches that may overlap (two streams, graph branches) get
 // different segments, and a segment comes round again only after kTicketPool / tiles (thousands of) later launches.  The address
 // is baked into a captured graph node; replays of a node serialize.
 constexpr unsigned kTicketPool = 1u << 20;
-unsigned* ticket_pool() {
-    static unsigned* pool = [] {
+constexpr int kTicketDevices = 64;
+struct TicketPool { unsigned* words = nullptr; std::atomic<unsigned> next{0}; std::once_flag once; };
+TicketPool* ticket_pool() {                             // the pool of the CURRENT device (one process may drive several)
+    static TicketPool pools[kTicketDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTicketDevices) return nullptr;
+    TicketPool* tp = &pools[dev];
+    std::call_once(tp->once, [tp] {
         unsigned* q = nullptr;
-        if (hipMalloc(&q, kTicketPool * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
-        if (hipMemset(q, 0, kTicketPool * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
-        return q;
-    }();
-    return pool;
+        if (hipMalloc(&q, kTicketPool * sizeof(unsigned)) == hipSuccess && hipMemset(q, 0, kTicketPool * sizeof(unsigned)) == hipSuccess)
+            tp->words = q;
+    });
+    return tp->words ? tp : nullptr;
 }
 unsigned* ticket_segment(unsigned n) {
-    static std::atomic<unsigned> next{0};
-    unsigned* pool = ticket_pool();
-    if (!pool || n > kTicketPool) return nullptr;
+    TicketPool* tp = ticket_pool();
+    if (!tp || n > kTicketPool) return nullptr;
     for (;;) {
-        unsigned at = next.load(std::memory_order_relaxed);
+        unsigned at = tp->next.load(std::memory_order_relaxed);
         const unsigned start = at + n > kTicketPool ? 0u : at;
-        if (next.compare_exchange_weak(at, start + n, std::memory_order_relaxed)) return pool + start;
+        if (tp->next.compare_exchange_weak(at, start + n, std::memory_order_relaxed)) return tp->words + start;
     }
 }
 

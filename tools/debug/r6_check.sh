@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r6check
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r6check/gpu_tests.log 2>&1; tail -3 gpurun_out/r6check/gpu_tests.log
+( time timeout 600 python bench.py ) > gpurun_out/r6check/bench_default.log 2>&1; grep "^{" gpurun_out/r6check/bench_default.log | cut -c1-200; grep real gpurun_out/r6check/bench_default.log
