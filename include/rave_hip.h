@@ -111,6 +111,23 @@ typedef struct rh_wn_bwd_item {
     int64_t cols;
 } rh_wn_bwd_item;
 int rh_weight_norm_bwd_batched_f32(const rh_wn_bwd_item* items, int32_t n_items, rh_stream_t stream);
+/* Batched reduction of the weight gradients' K-slice partials (round 6; the per-layer ordered reduction that follows every
+ * split weight-gradient kernel -- 56 launches per v2 step -- collected over several layers into one launch, the same sums in the
+ * same order).  rh_defer_reduce(item) arms the NEXT rh_conv1d_bwd_weight_f32 call of this thread (consumed by it, like
+ * rh_x6_set_ranges): where that call would launch the reduction of its partials it leaves them in its workspace and fills *item
+ * (part = the partials [Z][n] behind the bias scratch of the workspace, out = dw, n, Z > 1); item->Z = 0 when nothing is
+ * pending (dw is complete).  The caller keeps workspace and dw alive until rh_reduce_partials_batched_f32 has run on the same
+ * stream.  Reference site: the weight gradients autograd produces for every conv of rave/blocks.py:514-714 in
+ * rave/model.py:288-344. */
+typedef struct rh_reduce_item {
+    const float* part;
+    float* out;
+    int64_t n;
+    int32_t Z;
+    int32_t reserved;
+} rh_reduce_item;
+int rh_defer_reduce(rh_reduce_item* item);
+int rh_reduce_partials_batched_f32(const rh_reduce_item* items, int32_t n_items, rh_stream_t stream);
 
 /* Number of floats of the two packed (MFMA-friendly, K-major) copies of a weight tensor:
  * which = 0 -> operand of rh_conv1d_fwd_f32, which = 1 -> operand of rh_conv1d_bwd_data_f32. */

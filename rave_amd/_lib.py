@@ -40,6 +40,11 @@ class WnBwdItem(C.Structure):
                 ("dg", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64)]
 
 
+class ReduceItem(C.Structure):
+    """Mirror of ``rh_reduce_item`` (include/rave_hip.h)."""
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("Z", C.c_int32), ("reserved", C.c_int32)]
+
+
 class LossItem(C.Structure):
     """Mirror of ``rh_loss_item`` (include/rave_hip.h)."""
     _fields_ = [("value", C.c_void_p), ("w1_dev", C.c_void_p), ("w1", C.c_float), ("w2", C.c_float)]
@@ -72,6 +77,8 @@ def _load() -> C.CDLL:
         "rh_weight_norm_fwd_f32": ([P, P, I64, I64, P, P, P], C.c_int),
         "rh_weight_norm_bwd_f32": ([P, P, P, P, I64, I64, P, P, P], C.c_int),
         "rh_weight_norm_bwd_batched_f32": ([C.POINTER(WnBwdItem), I32, P], C.c_int),
+        "rh_defer_reduce": ([C.POINTER(ReduceItem)], C.c_int),
+        "rh_reduce_partials_batched_f32": ([C.POINTER(ReduceItem), I32, P], C.c_int),
         "rh_conv1d_packed_floats": ([D, C.c_int], I64),
         "rh_conv1d_pack_f32": ([D, P, P, P, P], C.c_int),
         "rh_conv1d_pack_wn_f32": ([D, P, P, P, P, P, P, P], C.c_int),

@@ -117,15 +117,14 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_kernel(const WgradP p) {
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              long n, int Z) {
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, float* __restrict__ out, long n, int Z, long block) {
     // A workgroup sums 64 consecutive elements; its four waves take the slices z = w, w + 4, w + 8, ... (eight independent
     // running sums each keep eight loads in flight per lane), then the four wave results are added in a fixed order: the
     // result is bitwise deterministic, and a small weight tensor with hundreds of K slices (the 96-channel layers:
     // 27 k elements x 256 slices) spreads over 4 x more workgroups and loads than one thread per element did.
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long e = (long)blockIdx.x * 64 + lane;
+    const long e = block * 64 + lane;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < n) {
         int z = w;
@@ -139,13 +138,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     __syncthreads();
     if (w == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              long n, int Z) {
+    reduce_partials_body(part, out, n, Z, blockIdx.x);
+}
 
 // Few slices of a large tensor (the wide layers: 1 ... 5 M weights x 2 ... 8 slices): one thread per FOUR consecutive elements,
 // 16-byte loads, all slices of a thread in flight (four running sums, fixed order -> deterministic).  The kernel above spends
 // a 256-thread workgroup on 64 elements, which is right for 27 k elements x 256 slices and wrong here (47 us for 75 MB).
-__global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                                   long n4, int Z) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void reduce_partials_vec4_body(const float* __restrict__ part, float* __restrict__ out, long n4, int Z,
+                                                          long block) {
+    const long e = block * 256 + threadIdx.x;
     if (e >= n4) return;
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(part) + e;
     f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -160,9 +163,40 @@ __global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* 
     for (; z < Z; ++z) s[0] += src[(long)z * n4];
     reinterpret_cast<f32x4*>(out)[e] = (s[0] + s[1]) + (s[2] + s[3]);
 }
+__global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                   long n4, int Z) {
+    reduce_partials_vec4_body(part, out, n4, Z, blockIdx.x);
+}
+
+// The reductions of SEVERAL layers in one launch (round 6: the v2 step ran 56 of them, one behind every weight-gradient kernel of
+// the side stream -- 0.70 ms of 9 - 15 us launches): a table BY VALUE of up to kReduceBatch items, each reduced by the workgroups
+// and in the summation order its own launch would have used (same bodies: the same bits).  rave_amd.ops collects the items of
+// consecutive layers (rh_defer_reduce: the weight-gradient call leaves its K-slice partials in its own scratch) and flushes
+// them every few layers on the side stream, and before the weight-norm backward / a data-parallel bucket needs the gradients.
+constexpr int kReduceBatch = 32;
+struct ReduceTable {
+    const float* part[kReduceBatch];
+    float* out[kReduceBatch];
+    long n[kReduceBatch];              // elements (vec4 items: groups of four)
+    long blk_begin[kReduceBatch + 1];  // prefix over the items' workgroups
+    int Z[kReduceBatch];
+    int vec4[kReduceBatch];
+    int items;
+};
+__global__ __launch_bounds__(256) void reduce_partials_batched_kernel(const ReduceTable tb) {
+    int it = 0;
+    while (it + 1 < tb.items && (long)blockIdx.x >= tb.blk_begin[it + 1]) ++it;      // (uniform: scalar loop over <= 32 entries)
+    const long block = (long)blockIdx.x - tb.blk_begin[it];
+    if (tb.vec4[it]) reduce_partials_vec4_body(tb.part[it], tb.out[it], tb.n[it], tb.Z[it], block);
+    else reduce_partials_body(tb.part[it], tb.out[it], tb.n[it], tb.Z[it], block);
+}
+
+static bool reduce_is_vec4(const float* part, const float* out, long n, int Z) {
+    return Z <= 16 && n >= (1l << 16) && (n & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0;
+}
 
 static void reduce_partials_go(const float* part, float* out, long n, int Z, hipStream_t stream) {
-    if (Z <= 16 && n >= (1l << 16) && (n & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0) {
+    if (reduce_is_vec4(part, out, n, Z)) {
         const long n4 = n / 4;
         hipLaunchKernelGGL(reduce_partials_vec4_kernel, dim3((unsigned)rh_cdiv64(n4, 256)), dim3(256), 0, stream, part, out, n4, Z);
     } else {
@@ -734,8 +768,45 @@ extern "C" int rh_weight_norm_bwd_f32(const float* dw, const float* v, const flo
 
 // tail != null: the weight is weight-normed (w = g v/||v||, dim 0 = the rows of dw in both conv directions) and the caller
 // wants dv, dg instead of dw: straight from the K-slice partials where the row fits (reduce_wn_bwd_kernel), else through dw.
+// rh_defer_reduce(item): the NEXT weight-gradient call of this thread may leave its K-slice partials unreduced in its scratch
+// and describe the pending reduction in *item (Z > 1) instead of launching it; item->Z = 0 when nothing is pending (the call
+// completed dw itself).  Consumed by that call.  The caller keeps scratch and dw alive and runs rh_reduce_partials_batched_f32.
+thread_local rh_reduce_item* g_defer_item = nullptr;
+extern "C" int rh_defer_reduce(rh_reduce_item* item) {
+    g_defer_item = item;
+    if (item) *item = rh_reduce_item{};
+    return RH_OK;
+}
+
+extern "C" int rh_reduce_partials_batched_f32(const rh_reduce_item* items, int32_t n_items, rh_stream_t stream) {
+    RH_REQUIRE(n_items >= 0 && (n_items == 0 || items), RH_ERR_INVALID, "reduce_partials_batched: bad arguments");
+    for (int i0 = 0; i0 < n_items; i0 += kReduceBatch) {
+        ReduceTable tb{};
+        long blocks = 0;
+        for (int i = i0; i < n_items && i < i0 + kReduceBatch; ++i) {
+            const rh_reduce_item& q = items[i];
+            if (q.Z <= 0 || q.n <= 0) continue;           // nothing pending for this layer
+            RH_REQUIRE(q.part && q.out, RH_ERR_INVALID, "reduce_partials_batched: null pointer in item %d", i);
+            const int k = tb.items++;
+            tb.part[k] = q.part; tb.out[k] = q.out; tb.Z[k] = q.Z;
+            tb.vec4[k] = reduce_is_vec4(q.part, q.out, q.n, q.Z) ? 1 : 0;
+            tb.n[k] = tb.vec4[k] ? q.n / 4 : q.n;
+            tb.blk_begin[k] = blocks;
+            blocks += tb.vec4[k] ? rh_cdiv64(tb.n[k], 256) : rh_cdiv64(q.n, 64);
+        }
+        if (tb.items == 0) continue;
+        tb.blk_begin[tb.items] = blocks;
+        RH_REQUIRE(blocks < 0x7fffffffl, RH_ERR_UNSUPPORTED, "reduce_partials_batched: too many workgroups");
+        hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb);
+        if (int e = rh_check_launch("reduce_partials_batched")) return e;
+    }
+    return RH_OK;
+}
+
 int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const float* alpha,
                  float* dw, float* dbias, void* ws, int64_t ws_bytes, hipStream_t stream, const RhWnTail* tail) {
+    rh_reduce_item* const defer = tail ? nullptr : g_defer_item;       // (consumed by this call whatever happens below)
+    g_defer_item = nullptr;
     WgradP p{};
     fill(d, &p);
     const unsigned *dy_range = nullptr, *x_range = nullptr;
@@ -780,9 +851,13 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
                        "conv1d_bwd_weight: workspace %lld B < %lld B", (long long)ws_bytes, (long long)x6);
             bool used = false;
             int left_z = 0;      // > 0: the partials were left unreduced in ws for the fused tail
-            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used, tail ? &left_z : nullptr,
+            if (int e = rh_wgrad_x6_launch(p, dw, fuse_bias ? dbias : nullptr, ws, stream, &used, (tail || defer) ? &left_z : nullptr,
                                            d->transposed ? x_range : dy_range, d->transposed ? dy_range : x_range))
                 return e;
+            if (used && left_z > 1 && defer) {        // the caller batches this layer's reduction with its neighbours'
+                defer->part = (const float*)ws; defer->out = dw; defer->n = nw; defer->Z = left_z;
+                return RH_OK;
+            }
             if (used && left_z > 1) {
                 bool fused = false;
                 if (int e = rh_reduce_wn_bwd_launch((const float*)ws, left_z, p.M, (long)p.C * p.T, tail->v, tail->g, tail->norms,
@@ -813,6 +888,10 @@ int rh_wgrad_run(const rh_conv1d_desc* d, const float* dy, const float* x, const
                                                  tail->dg, stream, &fused))
                 return e2;
             if (fused) return RH_OK;
+        }
+        if (defer) {
+            defer->part = (const float*)ws; defer->out = dw; defer->n = nw; defer->Z = w.Z;
+            return RH_OK;
         }
         reduce_partials_go((const float*)ws, dw, nw, w.Z, stream);
         return through_dw(rh_check_launch("conv1d_bwd_weight_reduce"));

@@ -471,8 +471,42 @@ def _wn_batch_enabled() -> bool:
     return os.environ.get("RH_WN_BATCH", "1") != "0"
 
 
+# The ordered reductions of the weight gradients' K-slice partials, collected the same way (round 6: 56 launches of 9 - 15 us per
+# v2 step, one behind every split weight-gradient kernel of the side stream): a weight-gradient call of the side stream leaves its
+# partials in a scratch of its own (rh_defer_reduce) and every RH_REDUCE_BATCH layers -- and whenever the gradients are needed: the
+# collected weight-norm launch, a data-parallel bucket, the join -- ONE launch reduces them all, each in the order its own launch
+# would have used (bit-identical; RH_REDUCE_BATCH=0: one launch per layer, at once).
+_RED_PENDING = []       # (ReduceItem, scratch tensor, dw tensor): the tensors are kept alive until the batch has been launched
+_RED_BATCH = 8
+
+
+def _reduce_batch() -> int:
+    """Layers per batched reduction; 0 = one launch per layer.  Default: 8 while a hipGraph is being recorded, 0 in eager steps --
+    there the per-layer scratch allocation and the extra calls cost more host time than the launches they save (measured: the
+    eager v2 step 9.5 -> 11.1 ms with batching, the replayed step unchanged at 232 instead of 281 dispatches).
+    RH_REDUCE_BATCH=n forces n in both modes (read per call: tests)."""
+    import os
+    e = os.environ.get("RH_REDUCE_BATCH")
+    if e is not None:
+        return int(e)
+    return _RED_BATCH if torch.cuda.is_current_stream_capturing() else 0
+
+
+def _flush_reduce_pending(stream_ptr) -> None:
+    items, _RED_PENDING[:] = list(_RED_PENDING), []
+    if not items:
+        return
+    arr = (L.ReduceItem * len(items))()
+    for a, (it, _, _) in zip(arr, items):
+        a.part, a.out, a.n, a.Z = it.part, it.out, it.n, it.Z
+    L.check(L.lib.rh_reduce_partials_batched_f32(arr, len(items), stream_ptr), "reduce_partials_batched")
+
+
 def _flush_wn_pending(stream_ptr) -> None:
+    _flush_reduce_pending(stream_ptr)        # (the weight-norm backward reads the reduced gradients)
     items, _WN_PENDING[:] = list(_WN_PENDING), []
+    if not items:
+        return
     arr = (L.WnBwdItem * len(items))()
     for a, (dw, v, g, norms, dv, dg) in zip(arr, items):
         a.dw, a.v, a.g, a.norms, a.dv, a.dg = L.ptr(dw), L.ptr(v), L.ptr(g), L.ptr(norms), L.ptr(dv), L.ptr(dg)
@@ -492,7 +526,7 @@ def side_stream_for_collective(device):
     if pend is None:
         return None
     side = pend[1]
-    if _WN_PENDING:
+    if _WN_PENDING or _RED_PENDING:
         with torch.cuda.stream(side):
             _flush_wn_pending(L.stream())
     side.wait_stream(torch.cuda.current_stream(device))
@@ -511,7 +545,7 @@ def join_side_streams() -> None:
     pend = _SIDE_PENDING[0]
     if pend is not None:
         main, side = pend[0], pend[1]
-        if _WN_PENDING:
+        if _WN_PENDING or _RED_PENDING:
             with torch.cuda.stream(side):
                 _flush_wn_pending(L.stream())
         main.wait_stream(side)
@@ -534,6 +568,7 @@ def abandon_side_streams(rejoin: bool = False) -> None:
     _SIDE_PENDING[0] = None
     _SIDE_HOLD.clear()
     _WN_PENDING.clear()
+    _RED_PENDING.clear()
 
 
 def _note_use(ctx, *params) -> None:
@@ -631,9 +666,12 @@ def _arm_wgrad_ranges(dy, x, s, d=None) -> None:
         L.lib.rh_x6_set_ranges(L.ptr(_range_of(dy, s, "wgrad dy")), L.ptr(_range_of(x, s, "wgrad x")), None, None)
 
 
-def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s):
+def _wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s, defer=None):
+    """``defer``: a ReduceItem -- the call may leave the reduction of its K-slice partials to the caller (rh_defer_reduce)."""
     def run(o_dw, o_db):
         _arm_wgrad_ranges(dy, x, s, d)
+        if defer is not None:
+            L.lib.rh_defer_reduce(C.byref(defer))
         return L.lib.rh_conv1d_bwd_weight_f32(C.byref(d), L.ptr(dy), L.ptr(x), L.ptr(alpha), L.ptr(o_dw), L.ptr(o_db), L.ptr(ws),
                                               nbytes, s)
 
@@ -741,7 +779,18 @@ def _wgrad_wn(d, dy, x, alpha, dw, db, v, g, norms, ws, nbytes, s, slot_v=None, 
     dv = _grad_out(slot_v, v.shape, v.device)
     dg = _grad_out(slot_g, g.shape, g.device)
     if side is not None and side.active and _wn_batch_enabled():
-        L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
+        nred = _reduce_batch()
+        if nred > 0:
+            # a scratch of its own (the caller's may be shared with the next weight gradient): the partials stay until the batch runs
+            own = torch.empty(max(nbytes, 4) // 4, device=dy.device, dtype=torch.float32)
+            item = L.ReduceItem()
+            L.check(_wgrad(d, dy, x, alpha, dw, db, own, nbytes, s, defer=item), "conv1d_bwd_weight")
+            if item.Z > 1:
+                _RED_PENDING.append((item, own, dw))
+                if len(_RED_PENDING) >= nred:
+                    _flush_reduce_pending(s)
+        else:
+            L.check(_wgrad(d, dy, x, alpha, dw, db, ws, nbytes, s), "conv1d_bwd_weight")
         # (aliases of dv / dg keep the storage alive until the batch has run; the tensor OBJECTS handed to autograd must have
         # no other holder, or AccumulateGrad clones -- i.e. reads -- them instead of adopting them)
         _WN_PENDING.append((dw, v, g, norms, dv.detach(), dg.detach()))

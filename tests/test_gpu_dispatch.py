@@ -790,6 +790,53 @@ def test_weight_gradient_with_the_input_staged_once_per_position_is_bit_identica
     assert rel_l2(dw1, dwf) < 2e-6 and rel_l2(db1, dbf) < 2e-6
 
 
+def test_batched_reduction_of_weight_gradient_partials_is_bit_identical(dev, monkeypatch):
+    """Round 6: the ordered reductions of the weight gradients' K-slice partials -- one launch behind every split weight-gradient
+    kernel of the side stream, 56 per v2 step -- are collected over RH_REDUCE_BATCH layers into one launch
+    (rh_defer_reduce + rh_reduce_partials_batched_f32; every tensor reduced by the workgroups and in the order its own launch
+    would have used).  Full-width v2 generator, forward + backward: every parameter gradient must be the SAME BITS with one launch
+    per layer (0), batches of 3 and batches of 8; and the batches really form (both reduction forms -- few slices of a large
+    tensor, hundreds of slices of a small one -- occur at this width)."""
+    from rave_amd import model as M, ops as R
+    counts = {}
+    real = R._flush_reduce_pending
+
+    def counting(stream_ptr):
+        n = len(R._RED_PENDING)
+        if n:
+            counts.setdefault("sizes", []).append(n)
+            counts.setdefault("kinds", set()).update("few" if it.Z <= 16 and it.n >= (1 << 16) else "many" for it, _, _ in R._RED_PENDING)
+        return real(stream_ptr)
+
+    monkeypatch.setattr(R, "_flush_reduce_pending", counting)
+
+    def run(nb):
+        counts.clear()
+        with _Env(RH_REDUCE_BATCH=nb):
+            torch.manual_seed(0)
+            m = M.build_v2().to(dev).train()
+            x = O.synthetic_batch(4, 1, 32768, seed=5).to(dev)
+            eps = torch.randn(4, 128, 16, generator=torch.Generator().manual_seed(1)).to(dev)
+            zp, _ = m.encode(x, return_mb=True)
+            z, reg = m.encoder.reparametrize(zp, eps)
+            y = m.decode(z)
+            (y.pow(2).mean() + 0.1 * reg).backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, dict(counts)
+
+    g0, c0 = run(0)
+    g8, c8 = run(8)
+    g3, c3 = run(3)
+    assert not c0                                             # nothing deferred
+    assert sum(c8["sizes"]) >= 40 and max(c8["sizes"]) == 8 and c8["kinds"] == {"few", "many"}, c8
+    assert sum(c3["sizes"]) == sum(c8["sizes"]) and max(c3["sizes"]) == 3, (c3, c8)
+    assert len(g0) > 100 and set(g0) == set(g8) == set(g3)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all()
+        assert torch.equal(g0[k], g8[k]), k
+        assert torch.equal(g0[k], g3[k]), k
+
+
 COMBINE_CASES = [
     # (name, batch, c_in, c_out, length, kernel, geometry kwargs, transposed) -- layers whose output tiles cannot fill the chip:
     # conv_x6.hip cuts K into slices (plan query: ksplit > 1)
