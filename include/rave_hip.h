@@ -197,7 +197,7 @@ int rh_residual_unit_fwd_f32(const rh_conv1d_desc* d3, const rh_conv1d_desc* d1,
  * upper bound within a factor of ~2^10 of it keeps f32 accuracy; a too SMALL value overflows f16: the slot must cover the
  * tensor).  rh_x6_set_ranges arms the slots of the NEXT rh_conv1d_fwd_f32 / rh_conv1d_bwd_data_f32 / rh_residual_unit_fwd_f32
  * / rh_conv1d_bwd_weight[_wn]_f32 / rh_conv2d_fwd_f32 / rh_conv2d_bwd_data_f32 / rh_conv2d_bwd_weight_f32 / rh_act_bwd_bias_f32
- * (out = the slot of g) call of this thread (consumed by that call, like rh_set_kernel_events):
+ * (out = the slot of g) / rh_pqmf_fold_k1_f32 / rh_reparam_fwd_f32 (out = the slot of their output) call of this thread (consumed by that call, like rh_set_kernel_events):
  *     in_a   weight gradient only: the slot of dy          in_b   the slot of the input activation (x; dy for bwd_data)
  *     out    where the call leaves max |output| (forward: y, bwd_data: dx; atomicMax, the caller zeroes it first) or NULL
  *     out2   rh_residual_unit_fwd_f32: the slot of the intermediate h, or NULL

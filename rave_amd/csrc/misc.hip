@@ -700,10 +700,13 @@ constexpr int kRpBlocks = 64;
 
 __device__ __forceinline__ float softplus_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// zs_range (round 6, optional): max |zs| goes to that range slot -- the decoder's first convolution reads its scale from there
 __global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ z, const float* __restrict__ eps, int C, int L,
-                                                          long n, float* __restrict__ zs, float* __restrict__ part) {
+                                                          long n, float* __restrict__ zs, float* __restrict__ part,
+                                                          unsigned* __restrict__ zs_range) {
     __shared__ float red[4];
-    float s = 0.f;
+    __shared__ float red_pub[4];
+    float s = 0.f, amax = 0.f;
     const long CL = (long)C * L;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const long b = e / CL, r = e - b * CL;
@@ -712,11 +715,14 @@ __global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restric
         // ATen chain it replaces -- the activations downstream are gated on its sign pattern
         const float sd = __fadd_rn(softplus_(scale), 1e-4f);
         const float var = __fmul_rn(sd, sd);
-        zs[e] = __fadd_rn(__fmul_rn(eps[e], sd), mean);
+        const float zv = __fadd_rn(__fmul_rn(eps[e], sd), mean);
+        zs[e] = zv;
+        amax = fmaxf(amax, fabsf(zv));
         s += __fsub_rn(__fsub_rn(__fadd_rn(__fmul_rn(mean, mean), var), logf(var)), 1.f);
     }
     const float t = block_sum(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (zs_range) rh_range_publish(zs_range, amax, blockIdx.x, red_pub);      // (uniform)
 }
 
 __global__ void reparam_finalize_kernel(const float* __restrict__ part, int nblocks, float inv, float* __restrict__ kl) {
@@ -751,10 +757,13 @@ extern "C" int64_t rh_reparam_workspace_bytes(void) { return (int64_t)kRpBlocks 
 
 extern "C" int rh_reparam_fwd_f32(const float* z, const float* eps, int32_t batch, int32_t c, int32_t l, float* zs, float* kl,
                                   void* workspace, int64_t workspace_bytes, rh_stream_t stream) {
+    unsigned* zs_range = nullptr;              // where max |zs| goes, if the caller armed an output slot (rh_x6_set_ranges)
+    rh_take_ranges(nullptr, nullptr, &zs_range, nullptr);
     RH_REQUIRE(z && eps && zs && kl && workspace && workspace_bytes >= rh_reparam_workspace_bytes(), RH_ERR_INVALID, "reparam_fwd: bad arguments");
     const long n = (long)batch * c * l;
     RH_REQUIRE(n > 0, RH_ERR_INVALID, "reparam_fwd: empty tensor");
-    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(kRpBlocks), dim3(256), 0, (hipStream_t)stream, z, eps, c, l, n, zs, (float*)workspace);
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(kRpBlocks), dim3(256), 0, (hipStream_t)stream, z, eps, c, l, n, zs, (float*)workspace,
+                       zs_range);
     if (int e = rh_check_launch("reparam_fwd")) return e;
     hipLaunchKernelGGL(reparam_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, kRpBlocks,
                        (float)(1.0 / ((double)batch * l)), kl);

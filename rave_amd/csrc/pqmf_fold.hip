@@ -149,20 +149,24 @@ bool fold_v2() {
 
 // second generation (pqmf_fold2.hip): matrix on the MFMA, sliding-window fold / overlap-add -- bit-identical outputs
 int rh_pqmf_fold_k1v2_launch(const float* in, const float* tab, int rows, int t_len, int n_frames, int o0, float scale, float* out,
-                             hipStream_t stream);
+                             hipStream_t stream, unsigned* out_range);
 int rh_pqmf_fold_k2v2_launch(const float* in, const float* tab, int rows, int n_frames, int n_out, int dp, float scale, float* out,
                              hipStream_t stream);
 
 extern "C" int rh_pqmf_fold_k1_f32(const float* in, const float* tab, int32_t rows, int32_t t_len, int32_t n_frames,
                                    int32_t o0, float scale, float* out, rh_stream_t stream) {
+    unsigned* out_range = nullptr;             // where max |out| goes, if the caller armed an output slot (rh_x6_set_ranges)
+    rh_take_ranges(nullptr, nullptr, &out_range, nullptr);
     RH_REQUIRE(rows >= 0 && t_len >= 0 && n_frames >= 0, RH_ERR_INVALID, "pqmf_fold_k1: bad sizes");
     if (rows == 0 || n_frames == 0) return RH_OK;
     RH_REQUIRE(in && tab && out, RH_ERR_INVALID, "pqmf_fold_k1: null pointer");
     if (fold_v2() && (long)t_len * 4 < 0x7fffffffl && (long)n_frames * 64 < 0x7fffffffl)
-        return rh_pqmf_fold_k1v2_launch(in, tab, rows, t_len, n_frames, o0, scale, out, (hipStream_t)stream);
+        return rh_pqmf_fold_k1v2_launch(in, tab, rows, t_len, n_frames, o0, scale, out, (hipStream_t)stream, out_range);
     hipLaunchKernelGGL(pqmf_fold_k1_kernel, dim3(rh_cdiv(n_frames, kFr1), rows), dim3(256), 0, (hipStream_t)stream, in, tab,
                        out, t_len, n_frames, o0, scale);
-    return rh_check_launch("pqmf_fold_k1");
+    if (int e = rh_check_launch("pqmf_fold_k1")) return e;
+    // (the first-generation kernel does not publish: a requested slot is filled by a pass over the output)
+    return out_range ? rh_amax_f32(out, (int64_t)rows * 16 * n_frames, out_range, stream) : RH_OK;
 }
 
 extern "C" int rh_pqmf_fold_k2_f32(const float* in, const float* tab, int32_t rows, int32_t n_frames, int32_t n_out,

@@ -28,9 +28,13 @@ constexpr int kSeg1 = 16 * (kF1 - 1) + kTaps;             // samples a workgroup
 constexpr int kWP = 34;                                   // pitch of a frame's 32 fold values in LDS (conflict-free MFMA reads)
 constexpr int kOP = kF1 + 4;                              // pitch of a band row in the output staging tile
 
+// out_range (round 6, optional): max |out| goes to that range slot (common.hpp) -- the first convolution of the encoder reads its
+// scale from there instead of from a separate rh_amax_f32 pass over the band tensor.
 __global__ __launch_bounds__(256) void pqmf_fold_k1v2_kernel(const float* __restrict__ in, const float* __restrict__ tab,
                                                              float* __restrict__ out, int t_len, int n_frames, int o0,
-                                                             float scale) {
+                                                             float scale, unsigned* __restrict__ out_range) {
+    __shared__ float red_pub[4];
+    float amax = 0.f;
     __shared__ __attribute__((aligned(16))) float xs[(kSeg1 + 255) / 256 * 256];
     __shared__ __attribute__((aligned(16))) float wb[kF1 * kWP];
     __shared__ __attribute__((aligned(16))) float ob[16 * kOP];
@@ -88,6 +92,9 @@ __global__ __launch_bounds__(256) void pqmf_fold_k1v2_kernel(const float* __rest
         const float se = (l16 & 1) ? -scale : scale;
         f32x4 o = {acc[0] * se, acc[1] * scale, acc[2] * se, acc[3] * scale};
         *reinterpret_cast<f32x4*>(ob + l16 * kOP + 32 * wave + 16 * nb + 4 * lg) = o;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            if (n0 + 32 * wave + 16 * nb + 4 * lg + r4 < n_frames) amax = fmaxf(amax, fabsf(o[r4]));
     }
     __syncthreads();
     // ---- whole band rows out: 16 bands x 128 frames, 16 bytes per lane
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(256) void pqmf_fold_k1v2_kernel(const float* __rest
                 if (n + e < n_frames) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), dst, base + 4u * e, 0, 0);
         }
     }
+    if (out_range) rh_range_publish(out_range, amax, blockIdx.x + blockIdx.y * 7u, red_pub);      // (uniform)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- K2
@@ -220,9 +228,9 @@ __global__ __launch_bounds__(256) void pqmf_fold_k2v2_kernel(const float* __rest
 }  // namespace
 
 int rh_pqmf_fold_k1v2_launch(const float* in, const float* tab, int rows, int t_len, int n_frames, int o0, float scale, float* out,
-                             hipStream_t stream) {
+                             hipStream_t stream, unsigned* out_range) {
     hipLaunchKernelGGL(pqmf_fold_k1v2_kernel, dim3(rh_cdiv(n_frames, kF1), rows), dim3(256), 0, stream, in, tab, out, t_len,
-                       n_frames, o0, scale);
+                       n_frames, o0, scale, out_range);
     return rh_check_launch("pqmf_fold_k1");
 }
 

@@ -1177,8 +1177,12 @@ class _PqmfAnalysisFn(torch.autograd.Function):
         y = torch.empty(rows, m, n_frames, device=x.device, dtype=torch.float32)
         if fold is not None:
             tab, lpad = fold
+            ry = _new_range(x.device) if _ranges_on() else None       # the kernel leaves max |y| for the encoder's first conv
+            if ry is not None:
+                L.lib.rh_x6_set_ranges(None, None, L.ptr(ry), None)
             L.check(L.lib.rh_pqmf_fold_k1_f32(L.ptr(x), L.ptr(tab), rows, t, n_frames, lpad - pad[0], 1.0, L.ptr(y), L.stream()),
                     "pqmf_fold_k1")
+            _attach_range(y, ry)
         else:
             L.check(L.lib.rh_pqmf_analysis_fwd_f32(L.ptr(x), L.ptr(w), rows, t, m, k, pad[0], n_frames, L.ptr(y), L.stream()),
                     "pqmf_analysis_fwd")
@@ -1641,8 +1645,12 @@ class _ReparamFn(torch.autograd.Function):
         kl = torch.empty((), device=z.device, dtype=torch.float32)
         nbytes = L.lib.rh_reparam_workspace_bytes()
         ws = torch.empty(nbytes // 4, device=z.device, dtype=torch.float32)
+        rz = _new_range(z.device) if _ranges_on() else None           # the kernel leaves max |zs| for the decoder's first conv
+        if rz is not None:
+            L.lib.rh_x6_set_ranges(None, None, L.ptr(rz), None)
         L.check(L.lib.rh_reparam_fwd_f32(L.ptr(z), L.ptr(eps), b, c, l, L.ptr(zs), L.ptr(kl), L.ptr(ws), nbytes, L.stream()),
                 "reparam_fwd")
+        _attach_range(zs, rz)
         ctx.save_for_backward(z, eps)
         return zs, kl
 
